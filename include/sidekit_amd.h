@@ -1,0 +1,121 @@
+/* sidekit_amd C ABI -- MI355X (gfx950) x-vector extraction and trial scoring.
+ *
+ * The reference (deep-privacy/sidekit) is pure Python and has no FFI layer: the drop-in boundary
+ * is its Python API.  This header is the C ABI that sits underneath the Python
+ * mirror in `sidekit_amd/` -- plain pointers and sizes, no torch types.  Each entry point names
+ * the reference interface it replaces (paths relative to the reference tree).
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative SK_E* class otherwise; the message is
+ *     available from xt_last_error() (thread-local).  No exception crosses the ABI.
+ *   - `d_` pointers are device (HIP) pointers owned by the caller, `h_` pointers are host memory.
+ *   - `stream` is a hipStream_t (NULL = default stream); calls are asynchronous on that stream.
+ *   - a handle is bound to the device current at xt_create() and is not thread-safe; handles on
+ *     different devices are independent (one process per GPU).
+ */
+#ifndef SIDEKIT_AMD_H
+#define SIDEKIT_AMD_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SK_OK 0
+#define SK_EARG (-1)       /* bad argument            -> AssertionError / ValueError in the shim */
+#define SK_ESHAPE (-2)     /* shape / key mismatch    -> RuntimeError (as torch load_state_dict) */
+#define SK_EHIP (-3)       /* HIP runtime error       -> RuntimeError                            */
+#define SK_EWORKSPACE (-4) /* batch exceeds xt_reserve -> RuntimeError                           */
+#define SK_ESTATE (-5)     /* call order (e.g. forward before finalize) -> RuntimeError          */
+
+enum { XT_ARCH_HALFRESNET34 = 0, XT_ARCH_TDNN = 1 };
+enum { XT_F32 = 0, XT_BF16 = 1, XT_F64 = 2, XT_I64 = 3 };
+enum { XT_LOSS_AAM = 0, XT_LOSS_CCE = 1 };
+
+typedef struct xt_handle xt_handle;
+
+/* Mirrors the arguments of sidekit.nnet.xvector.Xtractor.__init__ (sidekit/nnet/xvector.py:424-431)
+ * that matter at inference, plus the compute dtype of the trunk. */
+typedef struct xt_config {
+  int32_t arch;     /* XT_ARCH_*: model_archi "halfresnet34" (xvector.py:569-599) | "xvector" (:453-513) */
+  int32_t dtype;    /* XT_F32 (parity path, exact-f32 MFMA) | XT_BF16 (bf16 MFMA, f32 accumulate)     */
+  int32_t loss;     /* XT_LOSS_AAM | XT_LOSS_CCE                                                      */
+  int32_t n_spk;    /* speaker_number                                                                 */
+  int32_t emb_dim;  /* embedding_size (256)                                                           */
+  float aam_s;      /* ArcMarginProduct scale: 30 (halfresnet34) / 64 (xvector)                       */
+} xt_config;
+
+/* Xtractor(...) : build an empty model on the current device. */
+int xt_create(const xt_config* cfg, xt_handle** out);
+int xt_destroy(xt_handle* h);
+
+/* Xtractor.load_state_dict (sidekit/bin/extract_xvectors.py:86, strict=True): hand over one
+ * checkpoint tensor by its reference key name (host memory, contiguous, row-major `shape`).
+ * dtype: XT_F32, or XT_I64 for the `num_batches_tracked` counters.  Unknown keys and wrong shapes
+ * fail with SK_ESHAPE. */
+int xt_set_tensor(xt_handle* h, const char* key, const void* h_data, const int64_t* shape, int32_t ndim, int32_t dtype);
+/* Number of keys / i-th key name the architecture expects (for strict checking in the shim). */
+int xt_num_keys(xt_handle* h);
+const char* xt_key_name(xt_handle* h, int32_t i);
+/* Fold BatchNorm, repack to kernel layouts, upload.  Fails with SK_ESHAPE naming the first missing key. */
+int xt_finalize(xt_handle* h);
+
+/* Size the device workspace for batches up to max_batch utterances x max_samples samples each
+ * (TDNN: max_batch x max_samples bounds the total). */
+int xt_reserve(xt_handle* h, int32_t max_batch, int64_t max_samples);
+
+/* Xtractor.forward(x, is_eval=True) (sidekit/nnet/xvector.py:876-907).
+ *   d_wav       float32 [B][wav_ld] waveform, utterance b uses its first h_nsamples[b] samples
+ *   h_nsamples  NULL = every utterance has L samples
+ *   d_emb       float32 [B][emb_dim]  L2-normalised x-vectors (tuple slot 1 of the reference)
+ *   d_logits    float32 [B][n_spk] s*cos logits (tuple slot 0), or NULL to skip them */
+int xt_forward(xt_handle* h, const float* d_wav, int64_t wav_ld, const int32_t* h_nsamples, int32_t B, int64_t L,
+               float* d_emb, float* d_logits, void* stream);
+
+/* Same, entered after the front-end (everything after xvector.py:885): the features->embedding
+ * seam the parity fixtures are cut at.  d_feats float32 (B, 80, T) as MelSpecFrontEnd / MfccFrontEnd
+ * return it; h_frames NULL = all T. */
+int xt_forward_features(xt_handle* h, const float* d_feats, const int32_t* h_frames, int32_t B, int32_t T,
+                        float* d_emb, float* d_logits, void* stream);
+
+/* Front-end only: MelSpecFrontEnd.forward(is_eval=True) (sidekit/nnet/preprocessor.py:267-285) or
+ * MfccFrontEnd.forward (:113-124).  d_feats_out float32 (B, 80, T), T = 1 + L / hop. */
+int xt_features(xt_handle* h, const float* d_wav, int64_t wav_ld, const int32_t* h_nsamples, int32_t B, int64_t L,
+                float* d_feats_out, void* stream);
+
+/* forward(..., norm_embedding=False) (xvector.py:876,893-898): only observable for loss='cce', whose
+ * eval output is then the un-normalised linear6 output; the 'aam' branch always normalises (:903). */
+int xt_set_norm_embedding(xt_handle* h, int32_t on);
+
+/* Diagnostics for stage-wise parity tests: keep a device copy of intermediate activations of the
+ * next forward ("feats", "stem", "layer1".."layer4", "pooled", "pre_norm", TDNN: "conv1".."conv5").
+ * xt_debug_tap copies one to host (raw element type of the trunk: f32, or bf16 for XT_BF16 trunk
+ * activations) and returns its byte size in *bytes. */
+int xt_set_debug(xt_handle* h, int32_t on);
+int xt_debug_tap(xt_handle* h, const char* name, void* h_dst, size_t capacity, size_t* bytes);
+
+const char* xt_last_error(void);
+
+/* ---- trial scoring ------------------------------------------------------------------------- */
+
+/* sidekit.iv_scoring.cosine_scoring, the einsum of sidekit/iv_scoring.py:108-109: rows already
+ * L2-normalised by the caller (StatServer.norm_stat1).  d_out[i][j] = <E_i, T_j>, float32. */
+int sc_cosine(const float* d_E, int32_t Ne, const float* d_T, int32_t Nt, int32_t D, float* d_out, void* stream);
+
+/* sidekit.iv_scoring.fast_PLDA_scoring, sidekit/iv_scoring.py:448-462:
+ *   out[i][j] = scaling * ( 0.5 e_i' Phi e_i + 0.5 t_j' Phi t_j + cst + e_i' Psi t_j ),  float64.
+ * Phi, Psi (D x D, row-major) and cst come from the 256x256 float64 algebra that stays on the
+ * host (iv_scoring.py:428-446).  E, T are the centred (and optionally Vtrans-rotated) vectors. */
+int sc_plda_fast(const double* d_E, int32_t Ne, const double* d_T, int32_t Nt, int32_t D, const double* d_Phi,
+                 const double* d_Psi, double cst, double scaling, double* d_out, void* stream);
+
+/* Speaker-mean enrolment + cosine over a listed trial set, sidekit/bin/compute_spk_cosine.py:18-26:
+ * out[k] = <E[enr_idx[k]], T[tst_idx[k]]> / (|E| |T|), float32 in, float64 maths. */
+int sc_cosine_trials(const float* d_E, const float* d_T, int32_t D, const int32_t* d_enr_idx, const int32_t* d_tst_idx,
+                     int64_t n_trials, double* d_out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SIDEKIT_AMD_H */

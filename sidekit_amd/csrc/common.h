@@ -1,0 +1,92 @@
+// Shared device/host helpers for the sidekit_amd HIP library (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+
+#include "../../include/sidekit_amd.h"
+
+namespace sk {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// ---- error plumbing (no exception crosses the C ABI) -------------------------------------
+// error classes SK_OK / SK_E* come from the public header
+void set_error(const char* fmt, ...);
+const char* last_error();
+
+#define SK_HIP(call)                                                                          \
+  do {                                                                                        \
+    hipError_t e_ = (call);                                                                   \
+    if (e_ != hipSuccess) {                                                                   \
+      sk::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+      return SK_EHIP;                                                                     \
+    }                                                                                         \
+  } while (0)
+
+#define SK_CHECK(cond, code, ...)   \
+  do {                              \
+    if (!(cond)) {                  \
+      sk::set_error(__VA_ARGS__);   \
+      return code;                  \
+    }                               \
+  } while (0)
+
+#define SK_TRY(expr)            \
+  do {                          \
+    int rc_ = (expr);           \
+    if (rc_ != 0) return rc_;   \
+  } while (0)
+
+// ---- bf16 <-> f32 ----------------------------------------------------------------------
+struct bf16_t { uint16_t v; };
+
+__host__ __device__ inline float bf16_to_f32(uint16_t b) {
+  uint32_t u = ((uint32_t)b) << 16;
+  return __builtin_bit_cast(float, u);
+}
+// round-to-nearest-even; NaN stays NaN (quiet)
+__host__ __device__ inline uint16_t f32_to_bf16(float f) {
+  uint32_t u = __builtin_bit_cast(uint32_t, f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+  return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+__device__ inline uint32_t pack_bf16x2(float lo, float hi) {
+  return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+}
+
+template <typename T> struct elem;
+template <> struct elem<float> {
+  static constexpr int bytes = 4;
+  __device__ static inline float load(const float* p) { return *p; }
+};
+template <> struct elem<bf16_t> {
+  static constexpr int bytes = 2;
+};
+
+// rows after n stride-2 (k3, p1) convolutions: h -> floor((h-1)/2)+1 = ceil(h/2)
+__host__ __device__ inline int halve(int h, int n) {
+  for (int i = 0; i < n; ++i) h = (h + 1) >> 1;
+  return h;
+}
+
+// per-utterance feature frames: `frames` may be null (uniform batch)
+struct Lens {
+  const int* frames;  // device, [B] or nullptr
+  int uniform;        // used when frames == nullptr
+  __device__ inline int get(int b) const { return frames ? frames[b] : uniform; }
+};
+
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+}  // namespace sk

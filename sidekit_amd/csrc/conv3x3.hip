@@ -1,0 +1,278 @@
+// 3x3 (and strided 1x1) convolution + folded BatchNorm (+ReLU) (+SE plane sums) for the
+// HalfResNet34 trunk: reference BasicBlock.forward, sidekit/nnet/res_net.py:309-320 (K5/K6 of
+// SURVEY 2.3), built MI355X-first:
+//
+//  * activations are NHWC ([B][H=time][W=freq][C]); one workgroup owns TH full-width output rows,
+//    stages the (TH-1)*S+3 input rows (+1 zero column each side) ONCE in LDS and reads all nine
+//    taps from there, so HBM sees each input row ~(1 + 2/TH) times instead of 9;
+//  * the contraction runs on the matrix cores as an implicit GEMM D[cout][pos] += W[cout][k] *
+//    X[k][pos] (k = tap x cin) with 32x32 MFMA tiles: v_mfma_f32_32x32x16_bf16 for the bf16
+//    path, v_mfma_f32_32x32x2_f32 (exact f32 FMA chain) for the fp32 parity path;
+//  * weights are pre-packed on the host in MFMA *fragment order* (64 lanes x 16 B per k-step), so
+//    every wave streams its A operand from L2 with perfectly coalesced 1-KiB loads and the LDS is
+//    left to the activations;
+//  * positions sit on the MFMA lanes, channels in the accumulator registers: each lane ends up
+//    with 4 consecutive output channels per register group -> 8-B (bf16) / 16-B (f32) NHWC stores
+//    with the BN scale/shift, ReLU and the squeeze-excite plane sums fused in the epilogue;
+//  * per-utterance lengths: rows >= the utterance's own row count are read as zero
+//    padding and never written, so a padded batch reproduces each utterance run alone.
+#include "kernels.h"
+
+namespace sk {
+
+template <typename T> __device__ inline void mma_step(f32x16& acc, const uint4& w, const uint4& x);
+
+template <> __device__ inline void mma_step<bf16_t>(f32x16& acc, const uint4& w, const uint4& x) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, x), acc, 0, 0, 0);
+}
+template <> __device__ inline void mma_step<float>(f32x16& acc, const uint4& w, const uint4& x) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, w.x), __builtin_bit_cast(float, x.x), acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, w.y), __builtin_bit_cast(float, x.y), acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, w.z), __builtin_bit_cast(float, x.z), acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, w.w), __builtin_bit_cast(float, x.w), acc, 0, 0, 0);
+}
+
+template <typename T_, int CIN_, int COUT_, int S_, int WIN_, int TH_, int WM_, int WN_, int MW_, int NW_, int CK_, int TAPS_>
+struct ConvCfg {
+  using T = T_;
+  static constexpr int EB = elem<T_>::bytes;
+  static constexpr int CIN = CIN_, COUT = COUT_, S = S_, WIN = WIN_, TH = TH_, WM = WM_, WN = WN_, MW = MW_, NW = NW_, CK = CK_;
+  static constexpr int TAPS = TAPS_;             // 9 (3x3, pad 1) or 1 (1x1: centre tap only)
+  static constexpr int WOUT = WIN / S;
+  static constexpr int MT = TH * WOUT;           // positions per workgroup
+  static constexpr int NT = WN * NW * 32;        // output channels per workgroup
+  static constexpr int RIN = (TH - 1) * S + 3;   // staged input rows
+  static constexpr int WP = WIN + 2;             // staged input columns (zero column each side)
+  static constexpr int CB = CK * EB;             // channel bytes staged per position
+  static constexpr int PSTRIDE = CB + 16;        // +16 B: ds_read_b128 of 32 neighbouring positions is conflict-free
+  static constexpr int LDS = RIN * WP * PSTRIDE;
+  static constexpr int KS = CB / 32;             // MFMA k-steps (32 B of k) per tap per chunk
+  static constexpr int NCH = CIN / CK;           // channel chunks
+  static constexpr int KTOT = NCH * TAPS * KS;   // k-steps per output-channel tile
+  static_assert(MT == WM * MW * 32, "positions must tile into 32-row MFMA tiles");
+  static_assert(WM * WN == 4, "four waves per workgroup");
+  static_assert(COUT % NT == 0 && CIN % CK == 0 && CB % 32 == 0, "channel tiling");
+  static_assert(LDS <= 160 * 1024, "LDS budget");
+};
+
+template <class C>
+__global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
+  using T = typename C::T;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[C::LDS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int wm = wave / C::WN, wn = wave % C::WN;
+  const int tiles = (a.Hout + C::TH - 1) / C::TH;
+  const int b = blockIdx.x / tiles, tile = blockIdx.x % tiles;
+  const int ho0 = tile * C::TH;
+  const int hin_b = halve(a.lens.get(b), a.halvings_in);
+  const int hout_b = (C::S == 2) ? ((hin_b + 1) >> 1) : hin_b;
+  if (ho0 >= hout_b) return;  // nothing valid in this tile (its SE partial is never read)
+  const int n0 = blockIdx.y * C::NT + wn * C::NW * 32;
+
+  int base[C::MW];
+#pragma unroll
+  for (int i = 0; i < C::MW; ++i) {
+    const int m = (wm * C::MW + i) * 32 + r;
+    const int ho = m / C::WOUT, wo = m % C::WOUT;
+    base[i] = ((ho * C::S) * C::WP + wo * C::S) * C::PSTRIDE + h * 16;
+  }
+  f32x16 acc[C::MW][C::NW];
+#pragma unroll
+  for (int i = 0; i < C::MW; ++i)
+#pragma unroll
+    for (int j = 0; j < C::NW; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+
+  const uint4* wp = reinterpret_cast<const uint4*>(a.wpack) + (size_t)(n0 / 32) * C::KTOT * 64 + lane;
+  const unsigned char* in = reinterpret_cast<const unsigned char*>(a.in);
+  const int hi0 = ho0 * C::S - 1;
+
+  for (int ch = 0; ch < C::NCH; ++ch) {
+    if (ch) __syncthreads();
+    constexpr int CPP = C::CB / 16;
+    constexpr int NCHUNK = C::RIN * C::WP * CPP;
+    for (int idx = tid; idx < NCHUNK; idx += 256) {
+      const int pos = idx / CPP, cc = idx % CPP;
+      const int row = pos / C::WP, col = pos % C::WP;
+      const int hi = hi0 + row, wi = col - 1;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (hi >= 0 && hi < hin_b && wi >= 0 && wi < C::WIN)
+        v = *reinterpret_cast<const uint4*>(in + ((((size_t)b * a.Hin + hi) * C::WIN + wi) * C::CIN + ch * C::CK) * C::EB + cc * 16);
+      *reinterpret_cast<uint4*>(smem + pos * C::PSTRIDE + cc * 16) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < C::TAPS; ++t) {
+      const int tap = (C::TAPS == 9) ? t : 4;
+      const int toff = ((tap / 3) * C::WP + tap % 3) * C::PSTRIDE;
+#pragma unroll
+      for (int ks = 0; ks < C::KS; ++ks) {
+        uint4 wf[C::NW];
+#pragma unroll
+        for (int j = 0; j < C::NW; ++j) wf[j] = wp[((size_t)j * C::KTOT + (ch * C::TAPS + t) * C::KS + ks) * 64];
+#pragma unroll
+        for (int i = 0; i < C::MW; ++i) {
+          const uint4 xf = *reinterpret_cast<const uint4*>(smem + base[i] + toff + ks * 32);
+#pragma unroll
+          for (int j = 0; j < C::NW; ++j) mma_step<T>(acc[i][j], wf[j], xf);
+        }
+      }
+    }
+  }
+
+  // ---- epilogue: BN scale/shift (+ReLU) -> NHWC store; SE plane sums ------------------------
+  unsigned char* out = reinterpret_cast<unsigned char*>(a.out);
+#pragma unroll
+  for (int j = 0; j < C::NW; ++j) {
+    float ssum[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) ssum[q] = 0.f;
+    f32x4 sc[4], sh[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int cb = n0 + j * 32 + 8 * g + 4 * h;
+      sc[g] = *reinterpret_cast<const f32x4*>(a.scale + cb);
+      sh[g] = *reinterpret_cast<const f32x4*>(a.shift + cb);
+    }
+#pragma unroll
+    for (int i = 0; i < C::MW; ++i) {
+      const int m = (wm * C::MW + i) * 32 + r;
+      const int ho = ho0 + m / C::WOUT, wo = m % C::WOUT;
+      const bool valid = ho < hout_b;
+      unsigned char* op = out + ((((size_t)b * a.Hout + ho) * C::WOUT + wo) * C::COUT + n0 + j * 32 + 4 * h) * C::EB;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float x = acc[i][j][4 * g + q] * sc[g][q] + sh[g][q];
+          if (a.relu) x = fmaxf(x, 0.f);
+          v[q] = x;
+          ssum[4 * g + q] += valid ? x : 0.f;
+        }
+        if (valid) {
+          if constexpr (C::EB == 2) {
+            *reinterpret_cast<uint2*>(op + 8 * g * 2) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+          } else {
+            *reinterpret_cast<float4*>(op + 8 * g * 4) = make_float4(v[0], v[1], v[2], v[3]);
+          }
+        }
+      }
+    }
+    if (a.se_part) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        float s = ssum[q];
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        ssum[q] = s;
+      }
+      if (r == 0) {
+        float* sp = a.se_part + (((size_t)b * tiles + tile) * C::WM + wm) * C::COUT + n0 + j * 32 + 4 * h;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          *reinterpret_cast<float4*>(sp + 8 * g) = make_float4(ssum[4 * g], ssum[4 * g + 1], ssum[4 * g + 2], ssum[4 * g + 3]);
+      }
+    }
+  }
+}
+
+template <class C>
+static int launch_cfg(const ConvArgs& a, hipStream_t st) {
+  const int tiles = cdiv(a.Hout, C::TH);
+  dim3 grid((unsigned)(a.B * tiles), C::COUT / C::NT);
+  hipLaunchKernelGGL(conv3x3_kernel<C>, grid, dim3(256), 0, st, a);
+  SK_HIP(hipGetLastError());
+  return SK_OK;
+}
+
+// ---- the trunk's convolution shapes ---------------------------------------------------------
+//                      T      CIN COUT S WIN TH WM WN MW NW  CK TAPS
+using B_L1   = ConvCfg<bf16_t,  32,  32, 1, 80,  8, 4, 1, 5, 1, 32, 9>;
+using B_L1S  = ConvCfg<bf16_t,  32,  32, 1, 80,  8, 4, 1, 5, 1, 32, 1>;
+using B_L2A  = ConvCfg<bf16_t,  32,  64, 2, 80,  8, 2, 2, 5, 1, 32, 9>;
+using B_L2S  = ConvCfg<bf16_t,  32,  64, 2, 80,  8, 2, 2, 5, 1, 32, 1>;
+using B_L2   = ConvCfg<bf16_t,  64,  64, 1, 40,  8, 2, 2, 5, 1, 64, 9>;
+using B_L3A  = ConvCfg<bf16_t,  64, 128, 2, 40,  8, 1, 4, 5, 1, 64, 9>;
+using B_L3S  = ConvCfg<bf16_t,  64, 128, 2, 40,  8, 1, 4, 5, 1, 64, 1>;
+using B_L3   = ConvCfg<bf16_t, 128, 128, 1, 20,  8, 1, 4, 5, 1, 128, 9>;
+using B_L4A  = ConvCfg<bf16_t, 128, 256, 2, 20, 16, 1, 4, 5, 2, 64, 9>;
+using B_L4S  = ConvCfg<bf16_t, 128, 256, 2, 20, 16, 1, 4, 5, 2, 64, 1>;
+using B_L4   = ConvCfg<bf16_t, 256, 256, 1, 10, 16, 1, 4, 5, 2, 128, 9>;
+
+using F_L1   = ConvCfg<float,  32,  32, 1, 80,  8, 4, 1, 5, 1, 32, 9>;
+using F_L1S  = ConvCfg<float,  32,  32, 1, 80,  8, 4, 1, 5, 1, 32, 1>;
+using F_L2A  = ConvCfg<float,  32,  64, 2, 80,  8, 2, 2, 5, 1, 16, 9>;
+using F_L2S  = ConvCfg<float,  32,  64, 2, 80,  8, 2, 2, 5, 1, 16, 1>;
+using F_L2   = ConvCfg<float,  64,  64, 1, 40,  8, 2, 2, 5, 1, 64, 9>;
+using F_L3A  = ConvCfg<float,  64, 128, 2, 40,  8, 1, 4, 5, 1, 32, 9>;
+using F_L3S  = ConvCfg<float,  64, 128, 2, 40,  8, 1, 4, 5, 1, 32, 1>;
+using F_L3   = ConvCfg<float, 128, 128, 1, 20,  8, 1, 4, 5, 1, 128, 9>;
+using F_L4A  = ConvCfg<float, 128, 256, 2, 20, 16, 1, 4, 5, 2, 32, 9>;
+using F_L4S  = ConvCfg<float, 128, 256, 2, 20, 16, 1, 4, 5, 2, 32, 1>;
+using F_L4   = ConvCfg<float, 256, 256, 1, 10, 16, 1, 4, 5, 2, 64, 9>;
+
+template <class C>
+static void fill_geom(ConvGeom& g) {
+  g.cin = C::CIN; g.cout = C::COUT; g.stride = C::S; g.win = C::WIN; g.th = C::TH; g.wm = C::WM;
+  g.ck = C::CK; g.taps = C::TAPS; g.ks = C::KS; g.eb = C::EB;
+}
+
+#define SK_CONV_CASES(X) \
+  X(CONV_L1, L1) X(CONV_L1S, L1S) X(CONV_L2A, L2A) X(CONV_L2S, L2S) X(CONV_L2, L2) X(CONV_L3A, L3A) \
+  X(CONV_L3S, L3S) X(CONV_L3, L3) X(CONV_L4A, L4A) X(CONV_L4S, L4S) X(CONV_L4, L4)
+
+int conv_geom(int shape, int dtype, ConvGeom* g) {
+  switch (shape) {
+#define X(id, name)                                              \
+  case id:                                                       \
+    if (dtype == DT_BF16) fill_geom<B_##name>(*g); else fill_geom<F_##name>(*g); \
+    return SK_OK;
+    SK_CONV_CASES(X)
+#undef X
+  }
+  set_error("conv_geom: unknown conv shape %d", shape);
+  return SK_EARG;
+}
+
+int launch_conv(int shape, int dtype, const ConvArgs& a, hipStream_t st) {
+  switch (shape) {
+#define X(id, name) \
+  case id: return dtype == DT_BF16 ? launch_cfg<B_##name>(a, st) : launch_cfg<F_##name>(a, st);
+    SK_CONV_CASES(X)
+#undef X
+  }
+  set_error("launch_conv: unknown conv shape %d", shape);
+  return SK_EARG;
+}
+
+// Host-side packer: torch layout W[cout][cin][kh][kw] (f32) -> MFMA fragment order.
+// Fragment (ntile, kidx=(chunk,tap,ks)), lane (r = lane&31, h = lane>>5), element j:
+//   W[ntile*32 + r][chunk*CK + ks*KE + h*KE/2 + j][tap]      (KE = 32 B / element size)
+size_t conv_pack_bytes(const ConvGeom& g) { return (size_t)g.cout * g.cin * g.taps * g.eb; }
+
+void conv_pack_weights(const ConvGeom& g, const float* w, int kh_kw, void* dst) {
+  const int KE = 32 / g.eb, nch = g.cin / g.ck, ktot = nch * g.taps * g.ks;
+  for (int nt = 0; nt < g.cout / 32; ++nt)
+    for (int ch = 0; ch < nch; ++ch)
+      for (int t = 0; t < g.taps; ++t) {
+        const int tap = (g.taps == 9) ? t : (kh_kw == 9 ? 4 : 0);
+        for (int ks = 0; ks < g.ks; ++ks) {
+          const size_t kidx = (size_t)(ch * g.taps + t) * g.ks + ks;
+          for (int lane = 0; lane < 64; ++lane) {
+            const int r = lane & 31, h = lane >> 5;
+            for (int j = 0; j < KE / 2; ++j) {
+              const int co = nt * 32 + r, ci = ch * g.ck + ks * KE + h * (KE / 2) + j;
+              const float v = w[((size_t)co * g.cin + ci) * kh_kw + tap];
+              const size_t e = (((size_t)nt * ktot + kidx) * 64 + lane) * (KE / 2) + j;
+              if (g.eb == 2) reinterpret_cast<uint16_t*>(dst)[e] = f32_to_bf16(v);
+              else reinterpret_cast<float*>(dst)[e] = v;
+            }
+          }
+        }
+      }
+}
+
+}  // namespace sk

@@ -1,0 +1,155 @@
+// Generic fp32 GEMM on the matrix cores (v_mfma_f32_32x32x2_f32: bit-exact f32 FMA chain, no
+// reduced-precision path on gfx950) with pluggable A-operand loaders and a fused epilogue.
+// Serves every dense contraction of the path that is NOT a 3x3 trunk convolution:
+//   STFT-as-DFT and mel / DCT projections (torchaudio MelSpectrogram / MFCC semantics),
+//   attentive-pooling 1x1 convs (pooling.py:136-141), embedding linears (xvector.py:489-491,
+//   578-581), AAM cosine logits (loss.py:307-310), TDNN dilated conv1d stack (xvector.py:467-483),
+//   cosine trial scoring (iv_scoring.py:108-109).
+// Tile: 64x64x32 per 256-thread workgroup, four waves each owning a 32x32 accumulator;
+// global->register prefetch of tile k+1 overlaps the MFMAs of tile k; LDS rows padded to 36
+// floats so the ds_read_b128 fragment reads are bank-conflict free.
+#include "kernels.h"
+
+namespace sk {
+
+GemmArgs gemm_args() {
+  GemmArgs g;
+  memset(&g, 0, sizeof(g));
+  g.alpha = 1.f;
+  return g;
+}
+
+constexpr int BM = 64, BN = 64, BK = 32, LDT = BK + 4;
+
+struct LoadPlain {
+  __device__ static inline float4 load(const GemmArgs& g, int m, int k) {
+    long row = m;
+    int c = k;
+    if (g.kc) { row += (long)(k / g.kc) * g.dil; c = k % g.kc; }
+    if (m >= g.M || k >= g.K || row >= g.a_rows) return make_float4(0.f, 0.f, 0.f, 0.f);
+    if (g.a_bf16) {
+      const uint2 v = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(g.A) + row * g.lda + c);
+      return make_float4(bf16_to_f32(v.x & 0xffff), bf16_to_f32(v.x >> 16), bf16_to_f32(v.y & 0xffff), bf16_to_f32(v.y >> 16));
+    }
+    return *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(g.A) + row * g.lda + c);
+  }
+};
+
+struct LoadFrames {
+  // augmentation.py:70-74 pre-emphasis (reflect pad 1 on the left) folded into the STFT framing
+  // (torch.stft center=True, pad_mode='reflect'; hann window centred in the n_fft frame).
+  __device__ static inline float sample(const float* w, int L, int i, float coef) {
+    if (i < 0) i = -i;
+    if (i >= L) i = 2 * (L - 1) - i;
+    const int p = (i == 0) ? 1 : i - 1;
+    return w[i] - coef * w[p];
+  }
+  __device__ static inline float4 load(const GemmArgs& g, int m, int k) {
+    if (m >= g.M || k >= g.K) return make_float4(0.f, 0.f, 0.f, 0.f);
+    int b, t;
+    if (g.row_b) { b = g.row_b[m]; t = g.row_t[m]; } else { b = m / g.t_max; t = m % g.t_max; }
+    const int L = g.nsamples ? g.nsamples[b] : g.nsamples_uniform;
+    if (t > L / g.hop) return make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* w = reinterpret_cast<const float*>(g.A) + (long)b * g.wav_ld;
+    const int i0 = t * g.hop - g.K / 2 + k;
+    const float4 win = *reinterpret_cast<const float4*>(g.window + k);
+    return make_float4(win.x * sample(w, L, i0, g.preemph), win.y * sample(w, L, i0 + 1, g.preemph),
+                       win.z * sample(w, L, i0 + 2, g.preemph), win.w * sample(w, L, i0 + 3, g.preemph));
+  }
+};
+
+struct LoadPower {
+  __device__ static inline float4 load(const GemmArgs& g, int m, int k) {
+    if (m >= g.M || k >= g.K) return make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* p = reinterpret_cast<const float*>(g.A) + (long)m * g.lda + k;
+    const float4 re = *reinterpret_cast<const float4*>(p);
+    const float4 im = *reinterpret_cast<const float4*>(p + g.kc);
+    return make_float4(re.x * re.x + im.x * im.x, re.y * re.y + im.y * im.y, re.z * re.z + im.z * im.z,
+                       re.w * re.w + im.w * im.w);
+  }
+};
+
+template <class LA>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) float As[BM * LDT];
+  __shared__ __attribute__((aligned(16))) float Ws[BN * LDT];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  // staging assignment: 2 float4 of A and 2 of W per thread per k-tile
+  const int srow = tid >> 3, sk4 = (tid & 7) * 4;
+  float4 ra[2], rw[2];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int row = srow + q * 32;
+      ra[q] = LA::load(g, m0 + row, k0 + sk4);
+      const int n = n0 + row, k = k0 + sk4;
+      rw[q] = (n < g.N && k < g.K) ? *reinterpret_cast<const float4*>(g.W + (long)n * g.ldw + k)
+                                   : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  f32x16 acc;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+  const int nk = (g.K + BK - 1) / BK;
+  fetch(0);
+  for (int kt = 0; kt < nk; ++kt) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      *reinterpret_cast<float4*>(&As[(srow + q * 32) * LDT + sk4]) = ra[q];
+      *reinterpret_cast<float4*>(&Ws[(srow + q * 32) * LDT + sk4]) = rw[q];
+    }
+    __syncthreads();
+    if (kt + 1 < nk) fetch((kt + 1) * BK);
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 8) {
+      const float4 a = *reinterpret_cast<const float4*>(&As[(wm * 32 + r) * LDT + kk + 4 * h]);
+      const float4 b = *reinterpret_cast<const float4*>(&Ws[(wn * 32 + r) * LDT + kk + 4 * h]);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  // epilogue: D[row = (q&3) + 8*(q>>2) + 4*h][col = r]
+  const int n = n0 + wn * 32 + r;
+  if (n >= g.N) return;
+  const float bias = g.bias ? g.bias[n] : 0.f;
+  const float sc = g.scale ? g.scale[n] : 1.f, sh = g.scale ? g.shift[n] : 0.f;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int m = m0 + wm * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+    if (m >= g.M) continue;
+    float v = acc[q] + bias;
+    if (g.rowbias) v += g.rowbias[(long)(m / g.rows_per_group) * g.N + n];
+    switch (g.act) {
+      case ACT_RELU: v = fmaxf(v, 0.f); break;
+      case ACT_LRELU02: v = v > 0.f ? v : 0.2f * v; break;
+      case ACT_RELU_BN_TANH: v = tanhf(fmaxf(v, 0.f) * sc + sh); break;
+      case ACT_LOG_EPS: v = logf(v + 1e-6f); break;
+      default: break;
+    }
+    if (g.act != ACT_RELU_BN_TANH) v = v * sc + sh;
+    g.C[(long)m * g.ldc + n] = v * g.alpha;
+  }
+}
+
+int launch_gemm(const GemmArgs& g, hipStream_t s) {
+  SK_CHECK(g.M > 0 && g.N > 0 && g.K > 0, SK_EARG, "gemm: empty problem %dx%dx%d", g.M, g.N, g.K);
+  SK_CHECK(g.K % 4 == 0 && g.ldw % 4 == 0, SK_EARG, "gemm: K=%d / ldw=%ld must be multiples of 4", g.K, g.ldw);
+  SK_CHECK(g.a_mode != A_PLAIN || (g.lda % 4 == 0 && g.kc % 4 == 0), SK_EARG, "gemm: lda/kc alignment");
+  dim3 grid(cdiv(g.M, BM), cdiv(g.N, BN));
+  switch (g.a_mode) {
+    case A_PLAIN: hipLaunchKernelGGL(gemm_kernel<LoadPlain>, grid, dim3(256), 0, s, g); break;
+    case A_FRAMES: hipLaunchKernelGGL(gemm_kernel<LoadFrames>, grid, dim3(256), 0, s, g); break;
+    case A_POWER: hipLaunchKernelGGL(gemm_kernel<LoadPower>, grid, dim3(256), 0, s, g); break;
+    default: set_error("gemm: bad a_mode %d", g.a_mode); return SK_EARG;
+  }
+  SK_HIP(hipGetLastError());
+  return SK_OK;
+}
+
+}  // namespace sk

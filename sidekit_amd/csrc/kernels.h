@@ -1,0 +1,107 @@
+// Internal kernel-launcher interface of libsidekit_amd (not part of the C ABI).
+#pragma once
+#include "common.h"
+
+namespace sk {
+
+enum { DT_F32 = 0, DT_BF16 = 1, DT_F64 = 2, DT_I64 = 3 };
+
+// ---- conv3x3.hip ------------------------------------------------------------------------
+enum ConvShape {
+  CONV_L1 = 0, CONV_L1S, CONV_L2A, CONV_L2S, CONV_L2, CONV_L3A, CONV_L3S, CONV_L3, CONV_L4A, CONV_L4S, CONV_L4,
+  CONV_NSHAPES
+};
+
+struct ConvArgs {
+  const void* in;      // [B][Hin][WIN][CIN]   (bf16 or f32)
+  const void* wpack;   // fragment-ordered weights
+  const float* scale;  // [COUT] folded BatchNorm scale
+  const float* shift;  // [COUT] folded BatchNorm shift
+  void* out;           // [B][Hout][WOUT][COUT]
+  float* se_part;      // [B][tiles][WM][COUT] per-workgroup plane sums, or nullptr
+  Lens lens;           // feature frames per utterance
+  int halvings_in;     // stride-2 stages between the features and this conv's input
+  int B, Hin, Hout;    // allocated rows of in / out
+  int relu;
+};
+
+struct ConvGeom { int cin, cout, stride, win, th, wm, ck, taps, ks, eb; };
+
+int conv_geom(int shape, int dtype, ConvGeom* g);
+int launch_conv(int shape, int dtype, const ConvArgs& a, hipStream_t st);
+size_t conv_pack_bytes(const ConvGeom& g);
+void conv_pack_weights(const ConvGeom& g, const float* w, int kh_kw, void* dst);
+
+// ---- trunk_misc.hip -----------------------------------------------------------------------
+// stem: features (strides sf, st in elements) -> relu(bn(conv3x3 1->32)) NHWC [B][T][80][32]
+int launch_stem(const float* feats, long sb, long sf, long st, const float* w /*[32][9]*/, const float* scale,
+                const float* shift, void* out, int dtype, Lens lens, int B, int T, hipStream_t s);
+// SE gate: plane sums -> mean -> FC -> ReLU -> FC -> sigmoid
+int launch_se_gate(const float* se_part, int tiles, int wm, int th, const float* w1, const float* w2, float* gate,
+                   Lens lens, int halvings_out, int wout, int C, int B, hipStream_t s);
+// y = relu(o2 * gate[b][c] + sc)
+int launch_residual(const void* o2, const float* gate, const void* sc, void* y, int dtype, int B, long plane /*H*W*/,
+                    int C, hipStream_t s);
+
+// ---- gemm.hip ---------------------------------------------------------------------------
+// C[m][n] = epi( sum_k A(m,k) * W[n][k] ), fp32 MFMA (exact f32 FMA chain), W row-major [N][K].
+// A(m,k) comes from a loader:
+//   A_PLAIN  : A[(m + (k / kc) * dil) * lda + k % kc]  (kc == 0: A[m*lda + k]); f32 or bf16 rows
+//              -- the (kc, dil) form is a dilated "valid" conv1d over channel-contiguous rows (TDNN)
+//   A_FRAMES : window[k] * preemph(wav_b)[reflect(t*hop - win/2 + k)]   (STFT framing, row m = (b,t))
+//   A_POWER  : S[m][k]^2 + S[m][k + kc]^2                               (|DFT|^2 from [re | im] rows)
+enum { A_PLAIN = 0, A_FRAMES = 1, A_POWER = 2 };
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_LRELU02 = 2, ACT_RELU_BN_TANH = 3, ACT_LOG_EPS = 4 };
+struct GemmArgs {
+  int a_mode;
+  const void* A;        // f32 or bf16 rows (A_PLAIN); f32 wav [B][wav_ld] (A_FRAMES); f32 S (A_POWER)
+  int a_bf16;           // A element type (A_PLAIN only)
+  long lda;             // elements between consecutive rows of A
+  long a_rows;          // rows that exist in A (reads beyond return 0)
+  int kc, dil;          // see loader description
+  // A_FRAMES only
+  const float* window;  // [win]
+  const int* nsamples;  // [B] device, or null -> nsamples_uniform
+  int nsamples_uniform;
+  long wav_ld;
+  int hop, t_max;       // frames per utterance slot: row m -> (b = m / t_max, t = m % t_max)
+  const int* row_b;     // optional ragged map: row -> utterance, row -> frame
+  const int* row_t;
+  float preemph;
+  const float* W;       // [N][K]
+  long ldw;
+  float* C;             // [M][ldc]
+  long ldc;
+  int M, N, K;
+  const float* bias;    // [N] or null (added before the activation)
+  const float* rowbias; // [M / rows_per_group][N] or null: per-group bias (attention context term)
+  int rows_per_group;
+  int act;
+  const float* scale;   // [N] or null: applied after the activation (BatchNorm that follows it)
+  const float* shift;   // [N]
+  float alpha;          // final multiplier
+};
+GemmArgs gemm_args();   // zero-initialised, alpha = 1
+int launch_gemm(const GemmArgs& g, hipStream_t s);
+
+// ---- pool.hip ---------------------------------------------------------------------------
+// rows layout: x[(row0[b] + t) * ld + d], t < count[b]
+struct RowSpan {
+  const int* offsets;  // [B] device row offset per utterance, or null -> b * stride
+  int stride;
+  Lens lens;           // feature frames per utterance
+  int halvings;        // count = halve(frames, halvings) - shrink
+  int shrink;
+  __device__ inline int row0(int b) const { return offsets ? offsets[b] : b * stride; }
+  __device__ inline int count(int b) const { return halve(lens.get(b), halvings) - shrink; }
+};
+// out[b][0:D] = mean_t, out[b][D:2D] = unbiased std_t  (pooling.py:55-70)
+int launch_mean_std(const void* x, int x_bf16, long ld, int D, RowSpan rs, float* out, int B, hipStream_t s);
+// attentive statistics: w = softmax_t(e); mu = sum x w; rh = sqrt(clamp(sum x^2 w - mu^2, 1e-9)) (pooling.py:165-168)
+int launch_att_stats(const void* x, int x_bf16, const float* e, long ld, int D, RowSpan rs, float* out, int B, hipStream_t s);
+// per-(b, column) CMVN over rows: (x - mean) / sqrt(var_biased + eps), in place (InstanceNorm1d)
+int launch_cmvn(float* x, long ld, int D, RowSpan rs, float eps, int B, hipStream_t s);
+// x / ||x||_2 (loss.py:91-100) followed by F.normalize(eps=1e-12) (xvector.py:903)
+int launch_l2norm(const float* x, float* out, int D, int B, hipStream_t s);
+
+}  // namespace sk

@@ -1,0 +1,852 @@
+// C ABI of the extractor: model handle, checkpoint ingestion (BatchNorm folding + repacking to the
+// kernels' layouts), workspace, and the launch sequence of Xtractor.forward(is_eval=True)
+// (sidekit/nnet/xvector.py:876-907) for the two architectures in scope.
+#include <math.h>
+#include <stdarg.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/sidekit_amd.h"
+#include "kernels.h"
+
+namespace sk {
+
+static thread_local char g_err[1024] = "";
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+const char* last_error() { return g_err; }
+
+struct HostTensor {
+  std::vector<int64_t> shape;
+  std::vector<float> data;
+  bool set = false;
+  size_t numel() const { size_t n = 1; for (auto s : shape) n *= (size_t)s; return n; }
+};
+
+struct FrontCfg { int n_fft, win, hop, n_mels, n_out; double f_min, f_max; };
+static const FrontCfg MELSPEC = {1024, 400, 160, 80, 80, 90.0, 7600.0};      // xvector.py:570-573, preprocessor.py:216-226
+static const FrontCfg MFCCCFG = {2048, 1024, 512, 100, 80, 133.333, 6855.4976};  // preprocessor.py:65-76
+
+struct ConvLayer {
+  int shape;
+  void* wpack = nullptr;
+  float* scale = nullptr;
+  float* shift = nullptr;
+  ConvGeom g;
+};
+struct Block {
+  ConvLayer c1, c2, sc;
+  bool has_sc = false;
+  float* se_w1 = nullptr;
+  float* se_w2 = nullptr;
+  int C, li;
+};
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+  int ensure(size_t n) {
+    if (n <= bytes) return SK_OK;
+    if (p) SK_HIP(hipFree(p));
+    p = nullptr; bytes = 0;
+    SK_HIP(hipMalloc(&p, n));
+    bytes = n;
+    return SK_OK;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+};
+
+}  // namespace sk
+
+using namespace sk;
+
+struct xt_handle {
+  xt_config cfg;
+  int device = 0;
+  bool finalized = false;
+  std::vector<std::string> keys;               // expected checkpoint keys, reference order
+  std::map<std::string, HostTensor> tensors;   // host copies until finalize
+  std::vector<void*> dev_allocs;               // weight blobs
+
+  FrontCfg fc;
+  int nbp = 0;             // DFT bins padded to a multiple of 4
+  float* d_window = nullptr;
+  float* d_basis = nullptr;  // [2*nbp][win]
+  float* d_fbT = nullptr;    // [n_mels][nbp]
+  float* d_dctT = nullptr;   // [n_out][n_mels] (MFCC)
+
+  // halfresnet34
+  float* stem_w = nullptr; float* stem_scale = nullptr; float* stem_shift = nullptr;
+  std::vector<Block> blocks;
+  float *att_w1x = nullptr, *att_w1c = nullptr, *att_b1 = nullptr, *att_bn_scale = nullptr, *att_bn_shift = nullptr;
+  float *att_w2 = nullptr, *att_b2 = nullptr;
+  float *emb_w = nullptr, *emb_scale = nullptr, *emb_shift = nullptr, *emb_bias = nullptr;
+  float* head_wn = nullptr;  // row-normalised ArcMargin weight
+  // tdnn
+  struct TdnnLayer { float *w, *bias, *scale, *shift; int cin, cout, k, dil; };
+  std::vector<TdnnLayer> tdnn;
+
+  // workspace
+  int max_batch = 0; int64_t max_samples = 0;
+  DevBuf ws_S, ws_feat, ws_act[4], ws_se, ws_gate, ws_ctx, ws_rb, ws_h, ws_e, ws_pooled, ws_pre, ws_emb, ws_int, ws_ragged;
+  // pinned staging ring for per-utterance integers
+  static constexpr int RING = 4;
+  int* ring_host[RING] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ring_ev[RING];
+  bool ring_used[RING] = {false, false, false, false};
+  size_t ring_bytes = 0;
+  int ring_cur = 0;
+  bool norm_embedding = true;
+  // debug taps
+  bool debug = false;
+  struct Tap { DevBuf buf; size_t bytes = 0; };
+  std::map<std::string, Tap> taps;
+};
+
+namespace sk {
+
+// ---- expected checkpoint keys ------------------------------------------------------------------
+static void add_bn_keys(std::vector<std::pair<std::string, std::vector<int64_t>>>& k, const std::string& p, int64_t c) {
+  k.push_back({p + ".weight", {c}});
+  k.push_back({p + ".bias", {c}});
+  k.push_back({p + ".running_mean", {c}});
+  k.push_back({p + ".running_var", {c}});
+  k.push_back({p + ".num_batches_tracked", {}});
+}
+
+static const int HALF_PLANES[4] = {32, 64, 128, 256};
+static const int HALF_BLOCKS[4] = {3, 4, 6, 3};
+
+typedef std::vector<std::pair<std::string, std::vector<int64_t>>> KeyList;
+
+static KeyList expected_keys(const xt_config& c) {
+  KeyList k;
+  const int64_t E = c.emb_dim, S = c.n_spk;
+  if (c.arch == XT_ARCH_HALFRESNET34) {
+    k.push_back({"preprocessor.PreEmphasis.flipped_filter", {1, 1, 2}});
+    k.push_back({"preprocessor.MelSpec.spectrogram.window", {400}});
+    k.push_back({"preprocessor.MelSpec.mel_scale.fb", {513, 80}});
+    const std::string sn = "sequence_network";
+    k.push_back({sn + ".conv1.weight", {32, 1, 3, 3}});
+    add_bn_keys(k, sn + ".bn1", 32);
+    int in_planes = 32;
+    for (int li = 0; li < 4; ++li) {
+      const int64_t pl = HALF_PLANES[li];
+      for (int bi = 0; bi < HALF_BLOCKS[li]; ++bi) {
+        const std::string p = sn + ".layer" + std::to_string(li + 1) + "." + std::to_string(bi);
+        k.push_back({p + ".conv1.weight", {pl, in_planes, 3, 3}});
+        add_bn_keys(k, p + ".bn1", pl);
+        k.push_back({p + ".conv2.weight", {pl, pl, 3, 3}});
+        add_bn_keys(k, p + ".bn2", pl);
+        k.push_back({p + ".se.fc.0.weight", {pl / 16, pl}});
+        k.push_back({p + ".se.fc.2.weight", {pl, pl / 16}});
+        if (bi == 0) {  // res_net.py:302 with the tuple stride of :518: every layer's first block
+          k.push_back({p + ".shortcut.0.weight", {pl, in_planes, 1, 1}});
+          add_bn_keys(k, p + ".shortcut.1", pl);
+        }
+        in_planes = (int)pl;
+      }
+    }
+    k.push_back({"before_speaker_embedding.lin_be.weight", {E, 5120}});
+    add_bn_keys(k, "before_speaker_embedding.bn_be", E);
+    k.push_back({"stat_pooling.attention.0.weight", {128, 7680, 1}});
+    k.push_back({"stat_pooling.attention.0.bias", {128}});
+    add_bn_keys(k, "stat_pooling.attention.2", 128);
+    k.push_back({"stat_pooling.attention.4.weight", {2560, 128, 1}});
+    k.push_back({"stat_pooling.attention.4.bias", {2560}});
+    k.push_back({"after_speaker_embedding.weight", {S, E}});
+  } else {
+    k.push_back({"preprocessor.PreEmphasis.flipped_filter", {1, 1, 2}});
+    k.push_back({"preprocessor.MFCC.dct_mat", {100, 80}});
+    k.push_back({"preprocessor.MFCC.MelSpectrogram.spectrogram.window", {1024}});
+    k.push_back({"preprocessor.MFCC.MelSpectrogram.mel_scale.fb", {1025, 100}});
+    const int cin[5] = {80, 512, 512, 512, 512}, cout[5] = {512, 512, 512, 512, 1536}, ks[5] = {5, 3, 3, 1, 1};
+    for (int i = 0; i < 5; ++i) {
+      const std::string n = std::to_string(i + 1);
+      k.push_back({"sequence_network.conv" + n + ".weight", {cout[i], cin[i], ks[i]}});
+      k.push_back({"sequence_network.conv" + n + ".bias", {cout[i]}});
+      add_bn_keys(k, "sequence_network.batch_norm" + n, cout[i]);
+    }
+    k.push_back({"before_speaker_embedding.linear6.weight", {E, 3072}});
+    k.push_back({"before_speaker_embedding.linear6.bias", {E}});
+    if (c.loss == XT_LOSS_AAM) {
+      k.push_back({"after_speaker_embedding.weight", {S, E}});
+    } else {  // xvector.py:499-507 (training-only head; held, never run at eval)
+      add_bn_keys(k, "after_speaker_embedding.batch_norm6", 512);
+      k.push_back({"after_speaker_embedding.linear7.weight", {512, 512}});
+      k.push_back({"after_speaker_embedding.linear7.bias", {512}});
+      add_bn_keys(k, "after_speaker_embedding.batch_norm7", 512);
+      k.push_back({"after_speaker_embedding.linear8.weight", {S, 512}});
+      k.push_back({"after_speaker_embedding.linear8.bias", {S}});
+    }
+  }
+  return k;
+}
+
+// ---- uploads ----------------------------------------------------------------------------------
+static int upload(xt_handle* h, const void* src, size_t bytes, void** dst) {
+  void* p = nullptr;
+  SK_HIP(hipMalloc(&p, bytes ? bytes : 16));
+  if (bytes) SK_HIP(hipMemcpy(p, src, bytes, hipMemcpyHostToDevice));
+  h->dev_allocs.push_back(p);
+  *dst = p;
+  return SK_OK;
+}
+static int upload_f(xt_handle* h, const std::vector<float>& v, float** dst) { return upload(h, v.data(), v.size() * 4, (void**)dst); }
+
+static const std::vector<float>& T(xt_handle* h, const std::string& key) { return h->tensors[key].data; }
+
+static void fold_bn(xt_handle* h, const std::string& p, std::vector<float>& scale, std::vector<float>& shift) {
+  const auto &g = T(h, p + ".weight"), &b = T(h, p + ".bias"), &m = T(h, p + ".running_mean"), &v = T(h, p + ".running_var");
+  const size_t n = g.size();
+  scale.resize(n); shift.resize(n);
+  for (size_t i = 0; i < n; ++i) {
+    const float s = g[i] / sqrtf(v[i] + 1e-5f);  // eval-mode BatchNorm, eps 1e-5
+    scale[i] = s;
+    shift[i] = b[i] - m[i] * s;
+  }
+}
+
+static int make_conv(xt_handle* h, ConvLayer& L, int shape, const std::string& wkey, const std::string& bnkey) {
+  L.shape = shape;
+  SK_TRY(conv_geom(shape, h->cfg.dtype == XT_BF16 ? DT_BF16 : DT_F32, &L.g));
+  const HostTensor& w = h->tensors[wkey];
+  const int khkw = (int)(w.shape[2] * w.shape[3]);
+  SK_CHECK(w.shape[0] == L.g.cout && w.shape[1] == L.g.cin && khkw == L.g.taps, SK_ESHAPE, "conv %s: weight/shape table mismatch", wkey.c_str());
+  std::vector<unsigned char> packed(conv_pack_bytes(L.g));
+  conv_pack_weights(L.g, w.data.data(), khkw, packed.data());
+  SK_TRY(upload(h, packed.data(), packed.size(), &L.wpack));
+  std::vector<float> sc, sh;
+  fold_bn(h, bnkey, sc, sh);
+  SK_TRY(upload_f(h, sc, &L.scale));
+  SK_TRY(upload_f(h, sh, &L.shift));
+  return SK_OK;
+}
+
+static int build_frontend(xt_handle* h) {
+  const FrontCfg& f = h->fc;
+  const int nb = f.n_fft / 2 + 1;
+  h->nbp = (nb + 3) / 4 * 4;
+  const bool mel = h->cfg.arch == XT_ARCH_HALFRESNET34;
+  const std::string wk = mel ? "preprocessor.MelSpec.spectrogram.window" : "preprocessor.MFCC.MelSpectrogram.spectrogram.window";
+  const std::string fk = mel ? "preprocessor.MelSpec.mel_scale.fb" : "preprocessor.MFCC.MelSpectrogram.mel_scale.fb";
+  SK_TRY(upload_f(h, T(h, wk), &h->d_window));
+  // real-DFT basis restricted to the window support: frame sample k sits at n = left + k of the n_fft frame
+  const int left = (f.n_fft - f.win) / 2;
+  std::vector<float> basis((size_t)2 * h->nbp * f.win, 0.f);
+  for (int j = 0; j < nb; ++j)
+    for (int k = 0; k < f.win; ++k) {
+      const long ph = ((long)j * (left + k)) % f.n_fft;
+      const double ang = 2.0 * M_PI * (double)ph / (double)f.n_fft;
+      basis[(size_t)j * f.win + k] = (float)cos(ang);
+      basis[((size_t)h->nbp + j) * f.win + k] = (float)(-sin(ang));
+    }
+  SK_TRY(upload_f(h, basis, &h->d_basis));
+  const auto& fb = T(h, fk);  // [nb][n_mels]
+  std::vector<float> fbT((size_t)f.n_mels * h->nbp, 0.f);
+  for (int j = 0; j < nb; ++j)
+    for (int m = 0; m < f.n_mels; ++m) fbT[(size_t)m * h->nbp + j] = fb[(size_t)j * f.n_mels + m];
+  SK_TRY(upload_f(h, fbT, &h->d_fbT));
+  if (!mel) {
+    const auto& dct = T(h, "preprocessor.MFCC.dct_mat");  // [n_mels][n_out]
+    std::vector<float> dT((size_t)f.n_out * f.n_mels);
+    for (int m = 0; m < f.n_mels; ++m)
+      for (int o = 0; o < f.n_out; ++o) dT[(size_t)o * f.n_mels + m] = dct[(size_t)m * f.n_out + o];
+    SK_TRY(upload_f(h, dT, &h->d_dctT));
+  }
+  return SK_OK;
+}
+
+static std::vector<float> normalize_rows(const std::vector<float>& w, int rows, int cols) {
+  std::vector<float> o(w.size());
+  for (int r = 0; r < rows; ++r) {
+    double s = 0;
+    for (int c = 0; c < cols; ++c) s += (double)w[(size_t)r * cols + c] * w[(size_t)r * cols + c];
+    const float n = fmaxf((float)sqrt(s), 1e-12f);  // F.normalize eps
+    for (int c = 0; c < cols; ++c) o[(size_t)r * cols + c] = w[(size_t)r * cols + c] / n;
+  }
+  return o;
+}
+
+static int finalize_half(xt_handle* h) {
+  const std::string sn = "sequence_network";
+  SK_TRY(upload_f(h, T(h, sn + ".conv1.weight"), &h->stem_w));
+  std::vector<float> sc, sh;
+  fold_bn(h, sn + ".bn1", sc, sh);
+  SK_TRY(upload_f(h, sc, &h->stem_scale));
+  SK_TRY(upload_f(h, sh, &h->stem_shift));
+  static const int first_shape[4] = {CONV_L1, CONV_L2A, CONV_L3A, CONV_L4A};
+  static const int rest_shape[4] = {CONV_L1, CONV_L2, CONV_L3, CONV_L4};
+  static const int sc_shape[4] = {CONV_L1S, CONV_L2S, CONV_L3S, CONV_L4S};
+  for (int li = 0; li < 4; ++li)
+    for (int bi = 0; bi < HALF_BLOCKS[li]; ++bi) {
+      const std::string p = sn + ".layer" + std::to_string(li + 1) + "." + std::to_string(bi);
+      Block b;
+      b.C = HALF_PLANES[li]; b.li = li;
+      SK_TRY(make_conv(h, b.c1, bi == 0 ? first_shape[li] : rest_shape[li], p + ".conv1.weight", p + ".bn1"));
+      SK_TRY(make_conv(h, b.c2, rest_shape[li], p + ".conv2.weight", p + ".bn2"));
+      b.has_sc = bi == 0;
+      if (b.has_sc) SK_TRY(make_conv(h, b.sc, sc_shape[li], p + ".shortcut.0.weight", p + ".shortcut.1"));
+      SK_TRY(upload_f(h, T(h, p + ".se.fc.0.weight"), &b.se_w1));
+      SK_TRY(upload_f(h, T(h, p + ".se.fc.2.weight"), &b.se_w2));
+      h->blocks.push_back(b);
+    }
+  // attentive pooling: channel index of the reference is d = c*10 + f (pooling.py:156-160); the
+  // trunk's NHWC rows are d' = f*256 + c.  Permute the weights once instead of the activations.
+  const int C4 = 256, F4 = 10, D = C4 * F4;
+  auto perm = [&](int dp) { const int f = dp / C4, c = dp % C4; return c * F4 + f; };
+  const auto& w1 = T(h, "stat_pooling.attention.0.weight");  // [128][7680]
+  std::vector<float> w1x((size_t)128 * D), w1c((size_t)128 * 2 * D);
+  for (int o = 0; o < 128; ++o)
+    for (int dp = 0; dp < D; ++dp) {
+      const int d = perm(dp);
+      w1x[(size_t)o * D + dp] = w1[(size_t)o * 3 * D + d];
+      w1c[(size_t)o * 2 * D + dp] = w1[(size_t)o * 3 * D + D + d];
+      w1c[(size_t)o * 2 * D + D + dp] = w1[(size_t)o * 3 * D + 2 * D + d];
+    }
+  SK_TRY(upload_f(h, w1x, &h->att_w1x));
+  SK_TRY(upload_f(h, w1c, &h->att_w1c));
+  SK_TRY(upload_f(h, T(h, "stat_pooling.attention.0.bias"), &h->att_b1));
+  fold_bn(h, "stat_pooling.attention.2", sc, sh);
+  SK_TRY(upload_f(h, sc, &h->att_bn_scale));
+  SK_TRY(upload_f(h, sh, &h->att_bn_shift));
+  const auto& w2 = T(h, "stat_pooling.attention.4.weight");  // [2560][128]
+  const auto& b2 = T(h, "stat_pooling.attention.4.bias");
+  std::vector<float> w2p((size_t)D * 128), b2p(D);
+  for (int dp = 0; dp < D; ++dp) {
+    const int d = perm(dp);
+    memcpy(&w2p[(size_t)dp * 128], &w2[(size_t)d * 128], 128 * sizeof(float));
+    b2p[dp] = b2[d];
+  }
+  SK_TRY(upload_f(h, w2p, &h->att_w2));
+  SK_TRY(upload_f(h, b2p, &h->att_b2));
+  const int E = h->cfg.emb_dim;
+  const auto& lw = T(h, "before_speaker_embedding.lin_be.weight");  // [E][5120] = [mu(d) | rh(d)]
+  std::vector<float> lwp((size_t)E * 2 * D);
+  for (int o = 0; o < E; ++o)
+    for (int dp = 0; dp < D; ++dp) {
+      const int d = perm(dp);
+      lwp[(size_t)o * 2 * D + dp] = lw[(size_t)o * 2 * D + d];
+      lwp[(size_t)o * 2 * D + D + dp] = lw[(size_t)o * 2 * D + D + d];
+    }
+  SK_TRY(upload_f(h, lwp, &h->emb_w));
+  fold_bn(h, "before_speaker_embedding.bn_be", sc, sh);
+  SK_TRY(upload_f(h, sc, &h->emb_scale));
+  SK_TRY(upload_f(h, sh, &h->emb_shift));
+  SK_TRY(upload_f(h, normalize_rows(T(h, "after_speaker_embedding.weight"), h->cfg.n_spk, E), &h->head_wn));
+  return SK_OK;
+}
+
+static int finalize_tdnn(xt_handle* h) {
+  const int cin[5] = {80, 512, 512, 512, 512}, cout[5] = {512, 512, 512, 512, 1536}, ks[5] = {5, 3, 3, 1, 1}, dil[5] = {1, 2, 3, 1, 1};
+  for (int i = 0; i < 5; ++i) {
+    const std::string n = std::to_string(i + 1);
+    const auto& w = T(h, "sequence_network.conv" + n + ".weight");  // [cout][cin][k]
+    std::vector<float> wg((size_t)cout[i] * cin[i] * ks[i]);
+    for (int o = 0; o < cout[i]; ++o)
+      for (int c = 0; c < cin[i]; ++c)
+        for (int j = 0; j < ks[i]; ++j) wg[((size_t)o * ks[i] + j) * cin[i] + c] = w[((size_t)o * cin[i] + c) * ks[i] + j];
+    xt_handle::TdnnLayer L;
+    L.cin = cin[i]; L.cout = cout[i]; L.k = ks[i]; L.dil = dil[i];
+    SK_TRY(upload_f(h, wg, &L.w));
+    SK_TRY(upload_f(h, T(h, "sequence_network.conv" + n + ".bias"), &L.bias));
+    std::vector<float> sc, sh;
+    fold_bn(h, "sequence_network.batch_norm" + n, sc, sh);
+    SK_TRY(upload_f(h, sc, &L.scale));
+    SK_TRY(upload_f(h, sh, &L.shift));
+    h->tdnn.push_back(L);
+  }
+  SK_TRY(upload_f(h, T(h, "before_speaker_embedding.linear6.weight"), &h->emb_w));
+  SK_TRY(upload_f(h, T(h, "before_speaker_embedding.linear6.bias"), &h->emb_bias));
+  if (h->cfg.loss == XT_LOSS_AAM)
+    SK_TRY(upload_f(h, normalize_rows(T(h, "after_speaker_embedding.weight"), h->cfg.n_spk, h->cfg.emb_dim), &h->head_wn));
+  return SK_OK;
+}
+
+// ---- small layout kernels -----------------------------------------------------------------------
+// feats (B, F, T) reference layout <-> row-major rows [row0(b) + t][F]
+__global__ void bft_to_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, int F, int T, RowSpan rs) {
+  const int b = blockIdx.x, n = rs.count(b);
+  const long r0 = rs.row0(b);
+  for (int i = threadIdx.x; i < n * F; i += blockDim.x) {
+    const int t = i / F, f = i % F;
+    dst[(r0 + t) * F + f] = src[((long)b * F + f) * T + t];
+  }
+}
+__global__ void rows_to_bft_kernel(const float* __restrict__ src, float* __restrict__ dst, int F, int T, RowSpan rs) {
+  const int b = blockIdx.x, n = rs.count(b);
+  const long r0 = rs.row0(b);
+  for (int i = threadIdx.x; i < T * F; i += blockDim.x) {
+    const int f = i / T, t = i % T;
+    dst[((long)b * F + f) * T + t] = t < n ? src[(r0 + t) * F + f] : 0.f;
+  }
+}
+
+static int tap(xt_handle* h, const char* name, const void* src, size_t bytes, hipStream_t st) {
+  if (!h->debug) return SK_OK;
+  auto& t = h->taps[name];
+  SK_TRY(t.buf.ensure(bytes));
+  t.bytes = bytes;
+  SK_HIP(hipMemcpyAsync(t.buf.p, src, bytes, hipMemcpyDeviceToDevice, st));
+  return SK_OK;
+}
+
+struct BatchMeta {
+  int B = 0;
+  int T = 0;               // max feature frames
+  Lens lens{nullptr, 0};   // feature frames per utterance
+  const int* d_nsamples = nullptr;
+  int nsamples_uniform = 0;
+  // ragged (TDNN)
+  int R = 0;               // total rows
+  const int* d_offsets = nullptr;
+  const int* d_row_b = nullptr;
+  const int* d_row_t = nullptr;
+};
+
+// Per-utterance integers travel host -> device through a small ring of pinned staging slots, each
+// guarded by an event, so the call stays asynchronous and the source never goes out of scope.
+static int ring_begin(xt_handle* h) {
+  h->ring_cur = (h->ring_cur + 1) % xt_handle::RING;
+  if (h->ring_used[h->ring_cur]) SK_HIP(hipEventSynchronize(h->ring_ev[h->ring_cur]));
+  return SK_OK;
+}
+static int push_ints(xt_handle* h, const std::vector<int>& v, size_t slot_off, const int** dptr, hipStream_t st) {
+  int* base = (int*)h->ws_int.p;
+  SK_CHECK((slot_off + v.size()) * 4 <= h->ws_int.bytes, SK_EWORKSPACE, "integer workspace too small");
+  int* stage = h->ring_host[h->ring_cur] + slot_off;
+  memcpy(stage, v.data(), v.size() * 4);
+  SK_HIP(hipMemcpyAsync(base + slot_off, stage, v.size() * 4, hipMemcpyHostToDevice, st));
+  *dptr = base + slot_off;
+  return SK_OK;
+}
+static int ring_end(xt_handle* h, hipStream_t st) {
+  SK_HIP(hipEventRecord(h->ring_ev[h->ring_cur], st));
+  h->ring_used[h->ring_cur] = true;
+  return SK_OK;
+}
+
+static int frontend_rows(xt_handle* h, const float* d_wav, int64_t wav_ld, const BatchMeta& m, float* d_feat_rows, hipStream_t st) {
+  const FrontCfg& f = h->fc;
+  const int M = m.R ? m.R : m.B * m.T;
+  // 1) frames x DFT basis -> [re | im]
+  GemmArgs g = gemm_args();
+  g.a_mode = A_FRAMES; g.A = d_wav; g.wav_ld = wav_ld; g.window = h->d_window; g.nsamples = m.d_nsamples;
+  g.nsamples_uniform = m.nsamples_uniform; g.hop = f.hop; g.t_max = m.T; g.row_b = m.d_row_b; g.row_t = m.d_row_t;
+  g.preemph = 0.97f;
+  g.W = h->d_basis; g.ldw = f.win; g.C = (float*)h->ws_S.p; g.ldc = 2 * h->nbp; g.M = M; g.N = 2 * h->nbp; g.K = f.win;
+  SK_CHECK((size_t)M * 2 * h->nbp * 4 <= h->ws_S.bytes, SK_EWORKSPACE, "spectrum workspace too small (xt_reserve)");
+  SK_TRY(launch_gemm(g, st));
+  // 2) |.|^2 x mel filterbank, log(. + 1e-6)
+  GemmArgs p = gemm_args();
+  p.a_mode = A_POWER; p.A = h->ws_S.p; p.lda = 2 * h->nbp; p.kc = h->nbp;
+  p.W = h->d_fbT; p.ldw = h->nbp; p.M = M; p.N = f.n_mels; p.K = h->nbp; p.act = ACT_LOG_EPS;
+  const bool mfcc = h->cfg.arch == XT_ARCH_TDNN;
+  float* logmel = mfcc ? (float*)h->ws_act[3].p : d_feat_rows;
+  p.C = logmel; p.ldc = f.n_mels;
+  SK_TRY(launch_gemm(p, st));
+  if (mfcc) {  // 3) DCT-II (ortho) 100 -> 80
+    GemmArgs d = gemm_args();
+    d.a_mode = A_PLAIN; d.A = logmel; d.lda = f.n_mels; d.a_rows = M; d.W = h->d_dctT; d.ldw = f.n_mels;
+    d.C = d_feat_rows; d.ldc = f.n_out; d.M = M; d.N = f.n_out; d.K = f.n_mels;
+    SK_TRY(launch_gemm(d, st));
+  }
+  // 4) CMVN over the utterance's own frames
+  RowSpan rs{m.d_offsets, m.T, m.lens, 0, 0};
+  SK_TRY(launch_cmvn(d_feat_rows, f.n_out, f.n_out, rs, 1e-5f, m.B, st));
+  return SK_OK;
+}
+
+static int tail(xt_handle* h, int B, float* d_emb, float* d_logits, hipStream_t st) {
+  const int E = h->cfg.emb_dim;
+  SK_TRY(tap(h, "pre_norm", h->ws_pre.p, (size_t)B * E * 4, st));
+  if (!h->norm_embedding && h->cfg.loss == XT_LOSS_CCE) {  // xvector.py:893-898: cce + is_eval returns x as is
+    SK_HIP(hipMemcpyAsync(d_emb, h->ws_pre.p, (size_t)B * E * 4, hipMemcpyDeviceToDevice, st));
+    return SK_OK;
+  }
+  SK_TRY(launch_l2norm((const float*)h->ws_pre.p, d_emb, E, B, st));
+  if (d_logits) {
+    SK_CHECK(h->head_wn != nullptr, SK_ESTATE, "logits requested but the model has no cosine head (loss='cce' returns embeddings only)");
+    GemmArgs g = gemm_args();
+    g.A = d_emb; g.lda = E; g.a_rows = B; g.W = h->head_wn; g.ldw = E; g.C = d_logits; g.ldc = h->cfg.n_spk;
+    g.M = B; g.N = h->cfg.n_spk; g.K = E; g.alpha = h->cfg.aam_s;
+    SK_TRY(launch_gemm(g, st));
+  }
+  return SK_OK;
+}
+
+// HalfResNet34 from CMVN'ed features with element strides (sb, sf, st)
+static int half_from_feats(xt_handle* h, const float* feats, long sb, long sf, long stt, const BatchMeta& m, float* d_emb,
+                           float* d_logits, hipStream_t st) {
+  const int dt = h->cfg.dtype == XT_BF16 ? DT_BF16 : DT_F32;
+  const int EB = dt == DT_BF16 ? 2 : 4;
+  const int B = m.B, T = m.T;
+  int Hl[4];
+  for (int l = 0; l < 4; ++l) Hl[l] = halve(T, l);
+  const size_t act_bytes = (size_t)B * T * 80 * 32 * EB;
+  for (int i = 0; i < 4; ++i) SK_CHECK(act_bytes <= h->ws_act[i].bytes, SK_EWORKSPACE, "activation workspace too small: call xt_reserve(%d, >= %d frames)", B, T);
+  void *X = h->ws_act[0].p, *O1 = h->ws_act[1].p, *O2 = h->ws_act[2].p, *SC = h->ws_act[3].p;
+  SK_TRY(launch_stem(feats, sb, sf, stt, h->stem_w, h->stem_scale, h->stem_shift, X, dt, m.lens, B, T, st));
+  SK_TRY(tap(h, "stem", X, act_bytes, st));
+  int prev_li = 0;
+  for (size_t bi = 0; bi < h->blocks.size(); ++bi) {
+    Block& b = h->blocks[bi];
+    const int li = b.li;
+    const bool first = b.has_sc;
+    const int lin = first ? (li == 0 ? 0 : li - 1) : li;  // layer index of the block input
+    ConvArgs a;
+    a.lens = m.lens; a.B = B;
+    // conv1 (+bn1 +relu)
+    a.in = X; a.wpack = b.c1.wpack; a.scale = b.c1.scale; a.shift = b.c1.shift; a.out = O1; a.se_part = nullptr;
+    a.halvings_in = lin; a.Hin = Hl[lin]; a.Hout = Hl[li]; a.relu = 1;
+    SK_TRY(launch_conv(b.c1.shape, dt, a, st));
+    // conv2 (+bn2) with SE plane sums
+    a.in = O1; a.wpack = b.c2.wpack; a.scale = b.c2.scale; a.shift = b.c2.shift; a.out = O2; a.se_part = (float*)h->ws_se.p;
+    a.halvings_in = li; a.Hin = Hl[li]; a.Hout = Hl[li]; a.relu = 0;
+    SK_TRY(launch_conv(b.c2.shape, dt, a, st));
+    const void* shortcut = X;
+    if (first) {  // 1x1 conv (stride s) + bn on the block input
+      a.in = X; a.wpack = b.sc.wpack; a.scale = b.sc.scale; a.shift = b.sc.shift; a.out = SC; a.se_part = nullptr;
+      a.halvings_in = lin; a.Hin = Hl[lin]; a.Hout = Hl[li]; a.relu = 0;
+      SK_TRY(launch_conv(b.sc.shape, dt, a, st));
+      shortcut = SC;
+    }
+    const int wout = 80 >> li;
+    SK_TRY(launch_se_gate((const float*)h->ws_se.p, cdiv(Hl[li], b.c2.g.th), b.c2.g.wm, b.c2.g.th, b.se_w1, b.se_w2,
+                          (float*)h->ws_gate.p, m.lens, li, wout, b.C, B, st));
+    SK_TRY(launch_residual(O2, (const float*)h->ws_gate.p, shortcut, O1, dt, B, (long)Hl[li] * wout, b.C, st));
+    std::swap(X, O1);
+    const bool last_of_layer = (bi + 1 == h->blocks.size()) || (h->blocks[bi + 1].li != li);
+    if (last_of_layer) {
+      const std::string nm = "layer" + std::to_string(li + 1);
+      SK_TRY(tap(h, nm.c_str(), X, (size_t)B * Hl[li] * wout * b.C * EB, st));
+    }
+    prev_li = li;
+  }
+  (void)prev_li;
+  // ---- attentive statistics pooling (pooling.py:151-171), rows = (b, t'), columns d' = f*256 + c
+  const int H4 = Hl[3], D = 2560, R = B * H4;
+  const int xbf = dt == DT_BF16;
+  RowSpan rs{nullptr, H4, m.lens, 3, 0};
+  SK_TRY(launch_mean_std(X, xbf, D, D, rs, (float*)h->ws_ctx.p, B, st));
+  GemmArgs c = gemm_args();  // context term of attention.0: W1[:, 2560:] . [mean | std] + bias, once per utterance
+  c.A = h->ws_ctx.p; c.lda = 2 * D; c.a_rows = B; c.W = h->att_w1c; c.ldw = 2 * D; c.C = (float*)h->ws_rb.p; c.ldc = 128;
+  c.M = B; c.N = 128; c.K = 2 * D; c.bias = h->att_b1;
+  SK_TRY(launch_gemm(c, st));
+  GemmArgs g1 = gemm_args();  // attention.0 on x + ReLU + BatchNorm1d + tanh
+  g1.A = X; g1.a_bf16 = xbf; g1.lda = D; g1.a_rows = R; g1.W = h->att_w1x; g1.ldw = D; g1.C = (float*)h->ws_h.p; g1.ldc = 128;
+  g1.M = R; g1.N = 128; g1.K = D; g1.rowbias = (const float*)h->ws_rb.p; g1.rows_per_group = H4;
+  g1.act = ACT_RELU_BN_TANH; g1.scale = h->att_bn_scale; g1.shift = h->att_bn_shift;
+  SK_TRY(launch_gemm(g1, st));
+  GemmArgs g2 = gemm_args();  // attention.4
+  g2.A = h->ws_h.p; g2.lda = 128; g2.a_rows = R; g2.W = h->att_w2; g2.ldw = 128; g2.C = (float*)h->ws_e.p; g2.ldc = D;
+  g2.M = R; g2.N = D; g2.K = 128; g2.bias = h->att_b2;
+  SK_TRY(launch_gemm(g2, st));
+  SK_TRY(launch_att_stats(X, xbf, (const float*)h->ws_e.p, D, D, rs, (float*)h->ws_pooled.p, B, st));
+  SK_TRY(tap(h, "pooled", h->ws_pooled.p, (size_t)B * 2 * D * 4, st));
+  GemmArgs e = gemm_args();  // lin_be + bn_be (xvector.py:578-581)
+  e.A = h->ws_pooled.p; e.lda = 2 * D; e.a_rows = B; e.W = h->emb_w; e.ldw = 2 * D; e.C = (float*)h->ws_pre.p;
+  e.ldc = h->cfg.emb_dim; e.M = B; e.N = h->cfg.emb_dim; e.K = 2 * D; e.scale = h->emb_scale; e.shift = h->emb_shift;
+  SK_TRY(launch_gemm(e, st));
+  return tail(h, B, d_emb, d_logits, st);
+}
+
+// TDNN from CMVN'ed MFCC rows [R][80]
+static int tdnn_from_rows(xt_handle* h, const float* rows, const BatchMeta& m, float* d_emb, float* d_logits, hipStream_t st) {
+  const int R = m.R;
+  const float* in = rows;
+  int lda = 80;
+  float* bufs[2] = {(float*)h->ws_act[0].p, (float*)h->ws_act[1].p};
+  for (int i = 0; i < 5; ++i) {
+    const auto& L = h->tdnn[i];
+    float* out = bufs[i & 1];
+    SK_CHECK((size_t)R * L.cout * 4 <= h->ws_act[i & 1].bytes, SK_EWORKSPACE, "TDNN activation workspace too small (xt_reserve)");
+    GemmArgs g = gemm_args();
+    g.A = in; g.lda = lda; g.a_rows = R; g.kc = L.k > 1 ? L.cin : 0; g.dil = L.dil;
+    g.W = L.w; g.ldw = (long)L.cin * L.k; g.C = out; g.ldc = L.cout; g.M = R; g.N = L.cout; g.K = L.cin * L.k;
+    g.bias = L.bias; g.act = ACT_LRELU02; g.scale = L.scale; g.shift = L.shift;  // conv -> LeakyReLU(0.2) -> BatchNorm1d
+    SK_TRY(launch_gemm(g, st));
+    const std::string nm = "conv" + std::to_string(i + 1);
+    SK_TRY(tap(h, nm.c_str(), out, (size_t)R * L.cout * 4, st));
+    in = out; lda = L.cout;
+  }
+  RowSpan rs{m.d_offsets, 0, m.lens, 0, 14};  // context_size()-1 = 4 + 4 + 6 frames consumed by the valid convs
+  SK_TRY(launch_mean_std(in, 0, 1536, 1536, rs, (float*)h->ws_pooled.p, m.B, st));
+  SK_TRY(tap(h, "pooled", h->ws_pooled.p, (size_t)m.B * 3072 * 4, st));
+  GemmArgs e = gemm_args();  // linear6 (xvector.py:489-491)
+  e.A = h->ws_pooled.p; e.lda = 3072; e.a_rows = m.B; e.W = h->emb_w; e.ldw = 3072; e.C = (float*)h->ws_pre.p; e.ldc = h->cfg.emb_dim;
+  e.M = m.B; e.N = h->cfg.emb_dim; e.K = 3072; e.bias = h->emb_bias;
+  SK_TRY(launch_gemm(e, st));
+  return tail(h, m.B, d_emb, h->cfg.loss == XT_LOSS_AAM ? d_logits : nullptr, st);
+}
+
+static int make_meta(xt_handle* h, const int32_t* h_counts, int B, int64_t L_or_T, bool counts_are_samples, BatchMeta& m,
+                     hipStream_t st) {
+  const FrontCfg& f = h->fc;
+  m.B = B;
+  std::vector<int> frames(B), nsamp(B);
+  bool uniform = true;
+  int tmax = 0;
+  for (int b = 0; b < B; ++b) {
+    const int64_t c = h_counts ? h_counts[b] : L_or_T;
+    SK_CHECK(c > 0 && c <= L_or_T, SK_EARG, "utterance %d: length %lld outside (0, %lld]", b, (long long)c, (long long)L_or_T);
+    if (counts_are_samples) {
+      // torch.stft(center=True, pad_mode='reflect') needs n_fft/2 < L (RuntimeError in the reference otherwise)
+      SK_CHECK(c > f.n_fft / 2, SK_EARG, "utterance %d: %lld samples, reflect padding needs more than %d", b, (long long)c, f.n_fft / 2);
+      nsamp[b] = (int)c;
+      frames[b] = 1 + (int)(c / f.hop);
+    } else {
+      frames[b] = (int)c;
+    }
+    if (frames[b] != frames[0] || (counts_are_samples && nsamp[b] != nsamp[0])) uniform = false;
+    tmax = frames[b] > tmax ? frames[b] : tmax;
+  }
+  m.T = tmax;
+  const bool ragged = h->cfg.arch == XT_ARCH_TDNN;
+  if (ragged)
+    for (int b = 0; b < B; ++b) SK_CHECK(frames[b] >= 15, SK_EARG, "utterance %d: %d frames < TDNN context of 15", b, frames[b]);
+  size_t off = 0;
+  if (!(uniform && !ragged)) SK_TRY(ring_begin(h));
+  if (uniform && !ragged) {
+    m.lens = Lens{nullptr, frames[0]};
+    m.nsamples_uniform = counts_are_samples ? nsamp[0] : 0;
+  } else {
+    const int* p;
+    SK_TRY(push_ints(h, frames, off, &p, st)); off += B;
+    m.lens = Lens{p, 0};
+    if (counts_are_samples) { SK_TRY(push_ints(h, nsamp, off, &m.d_nsamples, st)); off += B; }
+  }
+  if (ragged) {
+    std::vector<int> offs(B), rb, rt;
+    int R = 0;
+    for (int b = 0; b < B; ++b) { offs[b] = R; R += frames[b]; }
+    rb.resize(R); rt.resize(R);
+    for (int b = 0; b < B; ++b)
+      for (int t = 0; t < frames[b]; ++t) { rb[offs[b] + t] = b; rt[offs[b] + t] = t; }
+    m.R = R;
+    SK_TRY(push_ints(h, offs, off, &m.d_offsets, st)); off += B;
+    SK_TRY(push_ints(h, rb, off, &m.d_row_b, st)); off += R;
+    SK_TRY(push_ints(h, rt, off, &m.d_row_t, st)); off += R;
+  }
+  if (!(uniform && !ragged)) SK_TRY(ring_end(h, st));
+  return SK_OK;
+}
+
+}  // namespace sk
+
+// ================================================================================================
+extern "C" {
+
+const char* xt_last_error(void) { return sk::last_error(); }
+
+int xt_create(const xt_config* cfg, xt_handle** out) {
+  SK_CHECK(cfg && out, SK_EARG, "xt_create: null argument");
+  SK_CHECK(cfg->arch == XT_ARCH_HALFRESNET34 || cfg->arch == XT_ARCH_TDNN, SK_EARG, "xt_create: unknown arch %d", cfg->arch);
+  SK_CHECK(cfg->dtype == XT_F32 || cfg->dtype == XT_BF16, SK_EARG, "xt_create: dtype must be XT_F32 or XT_BF16");
+  SK_CHECK(cfg->arch == XT_ARCH_HALFRESNET34 || cfg->dtype == XT_F32, SK_EARG, "xt_create: the TDNN runs in fp32 only");
+  SK_CHECK(cfg->loss == XT_LOSS_AAM || (cfg->loss == XT_LOSS_CCE && cfg->arch == XT_ARCH_TDNN), SK_EARG, "xt_create: unsupported loss for this arch");
+  SK_CHECK(cfg->n_spk > 0 && cfg->emb_dim > 0 && cfg->emb_dim % 4 == 0, SK_EARG, "xt_create: bad n_spk / emb_dim");
+  xt_handle* h = new xt_handle();
+  h->cfg = *cfg;
+  h->fc = cfg->arch == XT_ARCH_HALFRESNET34 ? MELSPEC : MFCCCFG;
+  int rc = hipGetDevice(&h->device);
+  if (rc != hipSuccess) { sk::set_error("hipGetDevice failed: %s", hipGetErrorString((hipError_t)rc)); delete h; return SK_EHIP; }
+  for (auto& kv : expected_keys(*cfg)) {
+    h->keys.push_back(kv.first);
+    HostTensor t; t.shape = kv.second;
+    h->tensors[kv.first] = t;
+  }
+  *out = h;
+  return SK_OK;
+}
+
+int xt_destroy(xt_handle* h) {
+  if (!h) return SK_OK;
+  for (void* p : h->dev_allocs) (void)hipFree(p);
+  DevBuf* bufs[] = {&h->ws_S, &h->ws_feat, &h->ws_act[0], &h->ws_act[1], &h->ws_act[2], &h->ws_act[3], &h->ws_se, &h->ws_gate,
+                    &h->ws_ctx, &h->ws_rb, &h->ws_h, &h->ws_e, &h->ws_pooled, &h->ws_pre, &h->ws_emb, &h->ws_int, &h->ws_ragged};
+  for (DevBuf* b : bufs) b->release();
+  for (auto& kv : h->taps) kv.second.buf.release();
+  for (int i = 0; i < xt_handle::RING; ++i)
+    if (h->ring_host[i]) { (void)hipHostFree(h->ring_host[i]); (void)hipEventDestroy(h->ring_ev[i]); }
+  delete h;
+  return SK_OK;
+}
+
+int xt_num_keys(xt_handle* h) { return h ? (int)h->keys.size() : 0; }
+const char* xt_key_name(xt_handle* h, int32_t i) { return (h && i >= 0 && i < (int)h->keys.size()) ? h->keys[i].c_str() : nullptr; }
+
+int xt_set_tensor(xt_handle* h, const char* key, const void* h_data, const int64_t* shape, int32_t ndim, int32_t dtype) {
+  SK_CHECK(h && key && (h_data || ndim == 0), SK_EARG, "xt_set_tensor: null argument");
+  SK_CHECK(!h->finalized, SK_ESTATE, "xt_set_tensor after xt_finalize");
+  auto it = h->tensors.find(key);
+  SK_CHECK(it != h->tensors.end(), SK_ESHAPE, "Unexpected key(s) in state_dict: \"%s\"", key);
+  HostTensor& t = it->second;
+  bool same = (size_t)ndim == t.shape.size();
+  for (int i = 0; same && i < ndim; ++i) same = shape[i] == t.shape[i];
+  if (!same) {
+    std::string got = "[", want = "[";
+    for (int i = 0; i < ndim; ++i) got += std::to_string(shape[i]) + (i + 1 < ndim ? ", " : "");
+    for (size_t i = 0; i < t.shape.size(); ++i) want += std::to_string(t.shape[i]) + (i + 1 < t.shape.size() ? ", " : "");
+    sk::set_error("size mismatch for %s: copying a param with shape %s], the shape in current model is %s]", key, got.c_str(), want.c_str());
+    return SK_ESHAPE;
+  }
+  const size_t n = t.numel();
+  t.data.resize(n);
+  if (dtype == XT_F32) memcpy(t.data.data(), h_data, n * 4);
+  else if (dtype == XT_I64) for (size_t i = 0; i < n; ++i) t.data[i] = (float)((const int64_t*)h_data)[i];
+  else if (dtype == XT_F64) for (size_t i = 0; i < n; ++i) t.data[i] = (float)((const double*)h_data)[i];
+  else { sk::set_error("xt_set_tensor: unsupported dtype %d for %s", dtype, key); return SK_EARG; }
+  t.set = true;
+  return SK_OK;
+}
+
+int xt_finalize(xt_handle* h) {
+  SK_CHECK(h, SK_EARG, "xt_finalize: null handle");
+  SK_CHECK(!h->finalized, SK_ESTATE, "xt_finalize called twice");
+  for (auto& k : h->keys) SK_CHECK(h->tensors[k].set, SK_ESHAPE, "Missing key(s) in state_dict: \"%s\"", k.c_str());
+  SK_HIP(hipSetDevice(h->device));
+  SK_TRY(build_frontend(h));
+  if (h->cfg.arch == XT_ARCH_HALFRESNET34) SK_TRY(finalize_half(h)); else SK_TRY(finalize_tdnn(h));
+  h->finalized = true;
+  return SK_OK;
+}
+
+int xt_reserve(xt_handle* h, int32_t max_batch, int64_t max_samples) {
+  SK_CHECK(h && max_batch > 0 && max_samples > 0, SK_EARG, "xt_reserve: bad arguments");
+  SK_HIP(hipSetDevice(h->device));
+  const FrontCfg& f = h->fc;
+  const size_t B = (size_t)max_batch;
+  const size_t T = 1 + (size_t)(max_samples / f.hop);
+  const size_t nbp = (size_t)((f.n_fft / 2 + 1 + 3) / 4 * 4);
+  const size_t R = B * T;
+  SK_TRY(h->ws_S.ensure(R * 2 * nbp * 4));
+  SK_TRY(h->ws_feat.ensure(R * f.n_out * 4));
+  const size_t int_bytes = (4 * B + 2 * R + 16) * 4;
+  SK_TRY(h->ws_int.ensure(int_bytes));
+  if (int_bytes > h->ring_bytes) {
+    for (int i = 0; i < xt_handle::RING; ++i) {
+      if (h->ring_host[i]) { if (h->ring_used[i]) SK_HIP(hipEventSynchronize(h->ring_ev[i])); SK_HIP(hipHostFree(h->ring_host[i])); }
+      else SK_HIP(hipEventCreateWithFlags(&h->ring_ev[i], hipEventDisableTiming));
+      SK_HIP(hipHostMalloc((void**)&h->ring_host[i], int_bytes, hipHostMallocDefault));
+      h->ring_used[i] = false;
+    }
+    h->ring_bytes = int_bytes;
+  }
+  const size_t E = (size_t)h->cfg.emb_dim;
+  SK_TRY(h->ws_pre.ensure(B * E * 4));
+  SK_TRY(h->ws_emb.ensure(B * E * 4));
+  if (h->cfg.arch == XT_ARCH_HALFRESNET34) {
+    const size_t EB = h->cfg.dtype == XT_BF16 ? 2 : 4;
+    for (int i = 0; i < 4; ++i) SK_TRY(h->ws_act[i].ensure(R * 80 * 32 * EB));
+    SK_TRY(h->ws_se.ensure(B * ((T + 7) / 8 + 1) * 4 * 32 * 4 * 2));
+    SK_TRY(h->ws_gate.ensure(B * 256 * 4));
+    const size_t H4 = (size_t)halve((int)T, 3);
+    SK_TRY(h->ws_ctx.ensure(B * 5120 * 4));
+    SK_TRY(h->ws_rb.ensure(B * 128 * 4));
+    SK_TRY(h->ws_h.ensure(B * H4 * 128 * 4));
+    SK_TRY(h->ws_e.ensure(B * H4 * 2560 * 4));
+    SK_TRY(h->ws_pooled.ensure(B * 5120 * 4));
+  } else {
+    SK_TRY(h->ws_act[0].ensure(R * 1536 * 4));
+    SK_TRY(h->ws_act[1].ensure(R * 512 * 4));
+    SK_TRY(h->ws_act[3].ensure(R * f.n_mels * 4));
+    SK_TRY(h->ws_pooled.ensure(B * 3072 * 4));
+  }
+  h->max_batch = max_batch; h->max_samples = max_samples;
+  return SK_OK;
+}
+
+static int check_run(xt_handle* h, int B, int64_t L_samples) {
+  SK_CHECK(h, SK_EARG, "null handle");
+  SK_CHECK(h->finalized, SK_ESTATE, "forward before xt_finalize (load_state_dict)");
+  SK_CHECK(B > 0, SK_EARG, "empty batch");
+  SK_CHECK(h->max_batch > 0, SK_ESTATE, "forward before xt_reserve");
+  SK_CHECK(B <= h->max_batch && L_samples <= h->max_samples, SK_EWORKSPACE,
+           "batch of %d x %lld samples exceeds the reserved workspace (%d x %lld): call xt_reserve", B, (long long)L_samples,
+           h->max_batch, (long long)h->max_samples);
+  SK_HIP(hipSetDevice(h->device));
+  return SK_OK;
+}
+
+int xt_forward(xt_handle* h, const float* d_wav, int64_t wav_ld, const int32_t* h_nsamples, int32_t B, int64_t L, float* d_emb,
+               float* d_logits, void* stream) {
+  SK_TRY(check_run(h, B, L));
+  SK_CHECK(d_wav && d_emb && wav_ld >= L, SK_EARG, "xt_forward: bad buffers");
+  hipStream_t st = (hipStream_t)stream;
+  BatchMeta m;
+  SK_TRY(make_meta(h, h_nsamples, B, L, true, m, st));
+  float* feat = (float*)h->ws_feat.p;
+  SK_TRY(frontend_rows(h, d_wav, wav_ld, m, feat, st));
+  const int M = m.R ? m.R : m.B * m.T;
+  SK_TRY(tap(h, "feats", feat, (size_t)M * h->fc.n_out * 4, st));
+  if (h->cfg.arch == XT_ARCH_HALFRESNET34) return half_from_feats(h, feat, (long)m.T * 80, 1, 80, m, d_emb, d_logits, st);
+  return tdnn_from_rows(h, feat, m, d_emb, d_logits, st);
+}
+
+int xt_forward_features(xt_handle* h, const float* d_feats, const int32_t* h_frames, int32_t B, int32_t T, float* d_emb,
+                        float* d_logits, void* stream) {
+  SK_TRY(check_run(h, B, (int64_t)(T > 0 ? T - 1 : 0) * (h ? h->fc.hop : 1)));
+  SK_CHECK(d_feats && d_emb && T > 0, SK_EARG, "xt_forward_features: bad buffers");
+  hipStream_t st = (hipStream_t)stream;
+  BatchMeta m;
+  SK_TRY(make_meta(h, h_frames, B, T, false, m, st));
+  if (h->cfg.arch == XT_ARCH_HALFRESNET34) {
+    m.T = T;  // rows are addressed through the caller's (B, 80, T) strides
+    return half_from_feats(h, d_feats, (long)80 * T, T, 1, m, d_emb, d_logits, st);
+  }
+  float* rows = (float*)h->ws_feat.p;
+  RowSpan rs{m.d_offsets, 0, m.lens, 0, 0};
+  hipLaunchKernelGGL(bft_to_rows_kernel, dim3(B), dim3(256), 0, st, d_feats, rows, 80, T, rs);
+  SK_HIP(hipGetLastError());
+  return tdnn_from_rows(h, rows, m, d_emb, d_logits, st);
+}
+
+int xt_features(xt_handle* h, const float* d_wav, int64_t wav_ld, const int32_t* h_nsamples, int32_t B, int64_t L,
+                float* d_feats_out, void* stream) {
+  SK_TRY(check_run(h, B, L));
+  SK_CHECK(d_wav && d_feats_out && wav_ld >= L, SK_EARG, "xt_features: bad buffers");
+  hipStream_t st = (hipStream_t)stream;
+  BatchMeta m;
+  SK_TRY(make_meta(h, h_nsamples, B, L, true, m, st));
+  float* feat = (float*)h->ws_feat.p;
+  SK_TRY(frontend_rows(h, d_wav, wav_ld, m, feat, st));
+  const int T = 1 + (int)(L / h->fc.hop);
+  RowSpan rs{m.d_offsets, m.T, m.lens, 0, 0};
+  hipLaunchKernelGGL(rows_to_bft_kernel, dim3(B), dim3(256), 0, st, feat, d_feats_out, h->fc.n_out, T, rs);
+  SK_HIP(hipGetLastError());
+  return SK_OK;
+}
+
+int xt_set_norm_embedding(xt_handle* h, int32_t on) {
+  SK_CHECK(h, SK_EARG, "null handle");
+  h->norm_embedding = on != 0;
+  return SK_OK;
+}
+
+int xt_set_debug(xt_handle* h, int32_t on) {
+  SK_CHECK(h, SK_EARG, "null handle");
+  h->debug = on != 0;
+  return SK_OK;
+}
+
+int xt_debug_tap(xt_handle* h, const char* name, void* h_dst, size_t capacity, size_t* bytes) {
+  SK_CHECK(h && name && bytes, SK_EARG, "xt_debug_tap: null argument");
+  auto it = h->taps.find(name);
+  SK_CHECK(it != h->taps.end(), SK_EARG, "xt_debug_tap: no tap named %s (xt_set_debug before forward?)", name);
+  *bytes = it->second.bytes;
+  if (!h_dst) return SK_OK;
+  SK_CHECK(capacity >= it->second.bytes, SK_EARG, "xt_debug_tap: buffer too small (%zu < %zu)", capacity, it->second.bytes);
+  SK_HIP(hipDeviceSynchronize());
+  SK_HIP(hipMemcpy(h_dst, it->second.buf.p, it->second.bytes, hipMemcpyDeviceToHost));
+  return SK_OK;
+}
+
+}  // extern "C"

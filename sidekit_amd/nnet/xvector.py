@@ -1,0 +1,300 @@
+"""``Xtractor`` -- host-side mirror of ``sidekit.nnet.xvector.Xtractor`` over the HIP library.
+
+Keeps the constructor / ``forward`` / ``load_state_dict`` / ``to`` / ``eval`` surface that
+``sidekit/bin/extract_xvectors.py:74-89,146`` and ``sidekit/nnet/xvector.py:1835-1843,1893`` use
+(reference ctor ``sidekit/nnet/xvector.py:424-431``, forward ``:876-907``), for the two
+architectures in scope (``model_archi='halfresnet34'`` and ``'xvector'``).  No ``torch.nn`` is
+involved: parameters are plain tensors kept in checkpoint layout, compute is
+``libsidekit_amd.so`` through ctypes, torch tensors only carry the input/output device memory
+and the stream.  There is no CPU fallback: running on a non-GPU device raises.
+"""
+import ctypes
+from collections import OrderedDict
+from types import SimpleNamespace
+
+import numpy
+import torch
+
+from .. import _lib
+from .preprocessor import MelSpecFrontEnd, MfccFrontEnd
+from .weights import seeded_state_dict, state_dict_spec
+
+
+def _ptr(arr):
+    return None if arr is None else arr.ctypes.data
+
+
+class _Params(SimpleNamespace):
+    """Attribute view on a group of checkpoint tensors (e.g. ``model.after_speaker_embedding.weight``)."""
+
+
+class Xtractor:
+    """x-vector extractor (inference).  Same positional/keyword arguments as the reference."""
+
+    def __init__(self, speaker_number, model_archi="xvector", loss=None, norm_embedding=False, aam_margin=0.2, aam_s=30,
+                 embedding_size=256, seed=None):
+        self.speaker_number = speaker_number
+        self.feature_size = None
+        self.norm_embedding = norm_embedding
+        self.embedding_size = embedding_size
+        print(f"MODEL = {model_archi}")  # reference ctor prints this (xvector.py:451)
+        if model_archi == "xvector":
+            if loss not in ["cce", "aam"]:
+                raise NotImplementedError("The valid loss are for now cce and aam ")
+            self.loss = loss
+            self.input_nbdim = 2
+            self.preprocessor = MfccFrontEnd(self)
+            self.feature_size = self.preprocessor.n_mfcc
+            self._arch, self._aam_s = _lib.XT_ARCH_TDNN, 64.0  # xvector.py:493-497
+        elif model_archi == "halfresnet34":
+            if loss != "aam":
+                raise NotImplementedError("halfresnet34 is built for loss='aam' (the released checkpoints); "
+                                          f"got loss={loss!r}")
+            self.loss = loss
+            self.preprocessor = MelSpecFrontEnd(self)
+            self._arch, self._aam_s = _lib.XT_ARCH_HALFRESNET34, 30.0  # xvector.py:586-591 (s=30, m=0.2 hard-coded)
+        else:
+            raise NotImplementedError(f"model_archi={model_archi!r}: only 'halfresnet34' and 'xvector' are built")
+        self.model_archi = model_archi
+        self.aam_margin, self.aam_s = aam_margin, self._aam_s
+        self._spec = state_dict_spec(model_archi, speaker_number, embedding_size, self.loss)
+        if seed is None:
+            seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+        self._sd = seeded_state_dict(model_archi, speaker_number, embedding_size, self.loss, seed)
+        self.device = torch.device("cpu")
+        self.training = True
+        self.compute_dtype = None  # None: follow torch autocast (reduced precision -> bf16 trunk), 'fp32' or 'bf16'
+        self._handles = {}
+        self._reserved = {}
+        self._refresh_views()
+
+    # ---- torch.nn.Module look-alikes -------------------------------------------------------------
+    def state_dict(self):
+        return OrderedDict((k, v.clone()) for k, v in self._sd.items())
+
+    def load_state_dict(self, state_dict, strict=True):
+        missing = [k for k in self._spec if k not in state_dict]
+        unexpected = [k for k in state_dict if k not in self._spec]
+        errors = []
+        if strict and unexpected:
+            errors.append("Unexpected key(s) in state_dict: " + ", ".join(f'"{k}"' for k in unexpected) + ". ")
+        if strict and missing:
+            errors.append("Missing key(s) in state_dict: " + ", ".join(f'"{k}"' for k in missing) + ". ")
+        for k, (shape, _) in self._spec.items():
+            if k in state_dict and tuple(state_dict[k].shape) != tuple(shape):
+                errors.append(f"size mismatch for {k}: copying a param with shape {tuple(state_dict[k].shape)} from checkpoint, "
+                              f"the shape in current model is {tuple(shape)}.")
+        if errors:
+            raise RuntimeError("Error(s) in loading state_dict for Xtractor:\n\t" + "\n\t".join(errors))
+        for k in self._spec:
+            if k in state_dict:
+                v = state_dict[k].detach().to("cpu")
+                self._sd[k] = v.to(torch.int64 if k.endswith("num_batches_tracked") else torch.float32).contiguous().clone()
+        self._drop_handles()
+        self._refresh_views()
+        return SimpleNamespace(missing_keys=missing, unexpected_keys=unexpected)
+
+    def to(self, device):
+        device = torch.device(device)
+        if device.type == "cuda" and device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        if device != self.device:
+            self._drop_handles()
+            self.device = device
+        return self
+
+    def cuda(self, device=None):
+        return self.to("cuda" if device is None else device)
+
+    def eval(self):
+        self.training = False
+        return self
+
+    def train(self, mode=True):
+        if mode:
+            raise NotImplementedError("training is out of scope for sidekit_amd (inference-only hot path)")
+        return self.eval()
+
+    def parameters(self):
+        return [v for k, v in self._sd.items() if self._spec[k][1] not in ("buffer", "count", "bn_m", "bn_v")]
+
+    def context_size(self):
+        """xvector.py:909-924: frames of context the conv stack named ``conv*`` consumes."""
+        if self.model_archi == "xvector":
+            return 1 + 4 * 1 + 2 * 2 + 2 * 3
+        return 1 + 2  # only `sequence_network.conv1` (the 3x3 stem) matches name.startswith("conv")
+
+    def __call__(self, *args, **kwargs):
+        return self.forward(*args, **kwargs)
+
+    # ---- compute ------------------------------------------------------------------------------
+    def forward(self, x, is_eval=False, target=None, norm_embedding=True, lengths=None):
+        """Reference ``forward`` (xvector.py:876-907) for extraction.
+
+        :param x: float32 waveform ``(L,)`` or ``(B, L)`` on the model's device
+        :param lengths: optional per-utterance sample counts for a zero-padded batch; each row is then
+            processed exactly as if run alone (no padding semantics exist in the reference)
+        :return: ``(s*cos logits (B, n_spk), x-vectors (B, E))`` for ``loss='aam'``; x-vectors for ``'cce'``
+        """
+        if not is_eval or target is not None:
+            raise NotImplementedError("sidekit_amd.Xtractor runs extraction only: call with is_eval=True and no target")
+        x = self._check_input(x)
+        B, L = x.shape
+        h = self._handle()
+        self._reserve(h, B, L)
+        lib = _lib.lib()
+        _lib.check(lib.xt_set_norm_embedding(h, 1 if norm_embedding else 0))
+        emb = torch.empty((B, self.embedding_size), dtype=torch.float32, device=x.device)
+        logits = torch.empty((B, int(self.speaker_number)), dtype=torch.float32, device=x.device) if self.loss == "aam" else None
+        lens = self._lengths(lengths, B, L)
+        _lib.check(lib.xt_forward(h, x.data_ptr(), x.stride(0), _ptr(lens), B, L, emb.data_ptr(),
+                                  logits.data_ptr() if logits is not None else None, self._stream(x)))
+        return (logits, emb) if self.loss == "aam" else emb
+
+    def forward_features(self, feats, frames=None, norm_embedding=True):
+        """Everything after ``xvector.py:885``: ``feats`` is the ``(B, 80, T)`` front-end output."""
+        feats = self._check_input(feats, dims=3)
+        B, F, T = feats.shape
+        if F != 80:
+            raise RuntimeError(f"expected (B, 80, T) features, got {tuple(feats.shape)}")
+        h = self._handle()
+        self._reserve(h, B, (T - 1) * self.preprocessor.hop_length + self.preprocessor.n_fft)
+        lib = _lib.lib()
+        _lib.check(lib.xt_set_norm_embedding(h, 1 if norm_embedding else 0))
+        emb = torch.empty((B, self.embedding_size), dtype=torch.float32, device=feats.device)
+        logits = torch.empty((B, int(self.speaker_number)), dtype=torch.float32, device=feats.device) if self.loss == "aam" else None
+        lens = self._lengths(frames, B, T)
+        _lib.check(lib.xt_forward_features(h, feats.data_ptr(), _ptr(lens), B, T, emb.data_ptr(),
+                                           logits.data_ptr() if logits is not None else None, self._stream(feats)))
+        return (logits, emb) if self.loss == "aam" else emb
+
+    def features(self, x, lengths=None):
+        """Front-end only (``MelSpecFrontEnd.forward(is_eval=True)`` / ``MfccFrontEnd.forward``): ``(B, 80, T)``."""
+        x = self._check_input(x)
+        B, L = x.shape
+        h = self._handle("fp32")
+        self._reserve(h, B, L)
+        T = 1 + L // self.preprocessor.hop_length
+        out = torch.empty((B, 80, T), dtype=torch.float32, device=x.device)
+        lens = self._lengths(lengths, B, L)
+        _lib.check(_lib.lib().xt_features(h, x.data_ptr(), x.stride(0), _ptr(lens), B, L, out.data_ptr(), self._stream(x)))
+        return out
+
+    def debug_taps(self, names, dtype=None):
+        """Intermediate activations of the last forward (after ``set_debug(True)``), as numpy arrays."""
+        h = self._handle(dtype)
+        lib = _lib.lib()
+        out = {}
+        for n in names:
+            nbytes = ctypes.c_size_t(0)
+            _lib.check(lib.xt_debug_tap(h, n.encode(), None, 0, ctypes.byref(nbytes)))
+            buf = numpy.empty(nbytes.value, dtype=numpy.uint8)
+            _lib.check(lib.xt_debug_tap(h, n.encode(), buf.ctypes.data, buf.nbytes, ctypes.byref(nbytes)))
+            out[n] = buf
+        return out
+
+    def set_debug(self, on, dtype=None):
+        _lib.check(_lib.lib().xt_set_debug(self._handle(dtype), 1 if on else 0))
+
+    # ---- plumbing ----------------------------------------------------------------------------
+    def _refresh_views(self):
+        groups = {}
+        for k, v in self._sd.items():
+            top, _, rest = k.partition(".")
+            groups.setdefault(top, {})[rest.replace(".", "_")] = v
+        for top in ("sequence_network", "stat_pooling", "before_speaker_embedding", "after_speaker_embedding"):
+            setattr(self, top, _Params(**groups.get(top, {})))
+
+    def _check_input(self, x, dims=2):
+        if not torch.is_tensor(x):
+            raise TypeError("input must be a torch tensor")
+        if self.device.type != "cuda":
+            raise RuntimeError("sidekit_amd.Xtractor computes on the GPU only (no CPU fallback): call .to('cuda') first")
+        if x.dim() == dims - 1:
+            x = x.unsqueeze(0)
+        if x.dim() != dims:
+            raise RuntimeError(f"expected a {dims - 1}-D or {dims}-D input, got shape {tuple(x.shape)}")
+        if x.device != self.device:
+            raise RuntimeError(f"input is on {x.device} but the model is on {self.device}")
+        if x.dtype != torch.float32:
+            x = x.float()
+        if x.stride(-1) != 1 or (dims == 3 and not x.is_contiguous()):
+            x = x.contiguous()
+        return x
+
+    @staticmethod
+    def _lengths(lengths, B, limit):
+        if lengths is None:
+            return None
+        arr = numpy.ascontiguousarray(torch.as_tensor(lengths).cpu().numpy().astype(numpy.int32))
+        if arr.shape != (B,):
+            raise ValueError(f"lengths must have shape ({B},)")
+        return arr
+
+    @staticmethod
+    def _stream(t):
+        return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+    def _dtype_key(self, dtype=None):
+        d = dtype or self.compute_dtype
+        if d is None:
+            d = "bf16" if (torch.is_autocast_enabled() and self.model_archi == "halfresnet34") else "fp32"
+        if d in ("bf16", torch.bfloat16):
+            if self.model_archi != "halfresnet34":
+                raise NotImplementedError("the TDNN runs in fp32 only")
+            return "bf16"
+        if d in ("fp32", "float32", torch.float32):
+            return "fp32"
+        raise ValueError(f"compute_dtype={d!r}: use 'fp32' or 'bf16'")
+
+    def _handle(self, dtype=None):
+        key = self._dtype_key(dtype)
+        if key in self._handles:
+            return self._handles[key]
+        if self.device.type != "cuda":
+            raise RuntimeError("sidekit_amd.Xtractor computes on the GPU only (no CPU fallback): call .to('cuda') first")
+        lib = _lib.lib()
+        cfg = _lib.XtConfig(self._arch, _lib.XT_BF16 if key == "bf16" else _lib.XT_F32,
+                            _lib.XT_LOSS_AAM if self.loss == "aam" else _lib.XT_LOSS_CCE, int(self.speaker_number),
+                            int(self.embedding_size), float(self._aam_s))
+        h = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(lib.xt_create(ctypes.byref(cfg), ctypes.byref(h)))
+            try:
+                for k, v in self._sd.items():
+                    a = v.numpy()
+                    shape = (ctypes.c_int64 * max(a.ndim, 1))(*a.shape)
+                    _lib.check(lib.xt_set_tensor(h, k.encode(), a.ctypes.data, shape, a.ndim,
+                                                 _lib.XT_I64 if a.dtype == numpy.int64 else _lib.XT_F32))
+                _lib.check(lib.xt_finalize(h))
+            except Exception:
+                lib.xt_destroy(h)
+                raise
+        self._handles[key] = h
+        self._reserved[key] = (0, 0)
+        return h
+
+    def _reserve(self, h, B, L):
+        key = next(k for k, v in self._handles.items() if v is h)
+        mb, ml = self._reserved[key]
+        if B > mb or L > ml:
+            mb, ml = max(B, mb), max(L, ml)
+            with torch.cuda.device(self.device):
+                torch.cuda.synchronize(self.device)
+                _lib.check(_lib.lib().xt_reserve(h, mb, ml))
+            self._reserved[key] = (mb, ml)
+
+    def _drop_handles(self):
+        if self._handles:
+            lib = _lib.lib()
+            if self.device.type == "cuda":
+                torch.cuda.synchronize(self.device)
+            for h in self._handles.values():
+                lib.xt_destroy(h)
+        self._handles, self._reserved = {}, {}
+
+    def __del__(self):
+        try:
+            self._drop_handles()
+        except Exception:
+            pass
