@@ -1,0 +1,203 @@
+#!/usr/bin/env python
+"""Headline benchmark: x-vectors/s for 4 s @ 16 kHz utterances, HalfResNet34, bf16 trunk.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the extraction hot path (Xtractor.forward(is_eval=True): wav -> 256-d
+x-vector) over one batch of 256 synthetic utterances already resident in HBM (BASELINE.json
+configs[1]); with N > 1 every rank (one process per GPU, launched by torch.distributed.run)
+extracts its own shard and the x-vectors are all-gathered over RCCL, as the scoring step needs
+them.  Timing: barrier + synchronize on both sides of exactly K steps, MAX over ranks, rank 0
+prints ONE JSON line.  Two extra objects ride on that line:
+
+  roofline     the dominant kernel (the trunk convolution shape with the largest summed device
+               time), its algorithmic bytes or FLOPs per launch over its mean launch duration
+               measured with HIP events on the launch stream during the timed steps;
+  cpu_baseline the oracle's CPU restatement of the same forward, timed on this box's host cores
+               on a bounded sample (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s
+MFMA_BF16_PEAK_TF = 2500.0   # dense bf16 MFMA
+MFMA_F32_PEAK_TF = 157.3     # f32-input MFMA == vector rate
+
+# trunk convolution shapes: name -> (cin, cout, stride, w_in, taps, layer index of the input, of the output)
+CONV_SHAPES = {
+    "conv_L1": (32, 32, 1, 80, 9, 0, 0), "conv_L1S": (32, 32, 1, 80, 1, 0, 0),
+    "conv_L2A": (32, 64, 2, 80, 9, 0, 1), "conv_L2S": (32, 64, 2, 80, 1, 0, 1), "conv_L2": (64, 64, 1, 40, 9, 1, 1),
+    "conv_L3A": (64, 128, 2, 40, 9, 1, 2), "conv_L3S": (64, 128, 2, 40, 1, 1, 2), "conv_L3": (128, 128, 1, 20, 9, 2, 2),
+    "conv_L4A": (128, 256, 2, 20, 9, 2, 3), "conv_L4S": (128, 256, 2, 20, 1, 2, 3), "conv_L4": (256, 256, 1, 10, 9, 3, 3),
+}
+
+
+def halve(h, n):
+    for _ in range(n):
+        h = (h + 1) // 2
+    return h
+
+
+def conv_work(name, B, T, eb):
+    """Algorithmic FLOPs and bytes of ONE launch of a trunk convolution (in + out of that conv)."""
+    cin, cout, s, win, taps, lin, lout = CONV_SHAPES[name]
+    hin, hout, wout = halve(T, lin), halve(T, lout), win // s
+    flops = 2.0 * B * hout * wout * cout * cin * taps
+    nbytes = (B * hin * win * cin + B * hout * wout * cout) * eb + cout * cin * taps * eb
+    return flops, nbytes
+
+
+def roofline(prof, B, T, dtype):
+    eb = 2 if dtype == "bf16" else 4
+    convs = {k: v for k, v in prof.items() if k in CONV_SHAPES}
+    if not convs:
+        return None
+    name = max(convs, key=lambda k: convs[k][0])
+    ms, n = convs[name]
+    dur = ms / n * 1e-3
+    flops, nbytes = conv_work(name, B, T, eb)
+    peak_tf = MFMA_BF16_PEAK_TF if dtype == "bf16" else MFMA_F32_PEAK_TF
+    ridge = peak_tf * 1e12 / (HBM_PEAK_GBS * 1e9)
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        with open(tpath) as f:
+            traffic = json.load(f).get(dtype, {}).get(name)
+    if flops / nbytes < ridge:
+        ach = nbytes / dur / 1e9
+        r = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS}
+    else:
+        ach = flops / dur / 1e12
+        r = {"bound": "mfma", "achieved": ach, "peak": peak_tf, "unit": "TFLOP/s", "frac": ach / peak_tf}
+    r.update({"traffic": traffic, "kernel": f"conv3x3_kernel<{name[5:]}, {dtype}>", "launch_us": dur * 1e6, "launches": n,
+              "alg_bytes_per_launch": nbytes, "alg_flops_per_launch": flops,
+              "per_class_ms_per_step": None})
+    return r
+
+
+def cpu_baseline(seconds, budget_s=12.0):
+    """The oracle (torch-CPU restatement of the reference forward) on this box's host cores."""
+    import torch
+    from oracle import xvector as oxv
+    from sidekit_amd.nnet.weights import seeded_state_dict
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    cores = min(cores, 16)  # a one-GPU box's CPU share; more threads only oversubscribe the intra-op pool
+    torch.set_num_threads(cores)
+    sd = seeded_state_dict("halfresnet34", 7205, seed=1234)
+    B = 8
+    torch.manual_seed(0)
+    wav = 0.1 * torch.randn(B, int(seconds * 16000))
+    with torch.no_grad():
+        oxv.halfresnet34_forward(wav, sd)  # warm-up
+        t0 = time.perf_counter()
+        it = 0
+        while time.perf_counter() - t0 < budget_s and it < 64:
+            oxv.halfresnet34_forward(wav, sd)
+            it += 1
+        dt = time.perf_counter() - t0
+    return {"value": B * it / dt, "unit": "x-vectors/s", "cores": cores, "kind": "port",
+            "sample": f"{it} batches of {B} synthetic {seconds:g} s utterances, fp32, torch-CPU oracle (oracle/xvector.py)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--seconds", type=float, default=4.0)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--arch", default="halfresnet34", choices=["halfresnet34", "xvector"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from sidekit_amd.nnet import Xtractor
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with torch.distributed.run)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    dtype = args.dtype if args.arch == "halfresnet34" else "fp32"
+    model = Xtractor(7205, model_archi=args.arch, loss="aam", seed=1234).to(dev).eval()
+    model.compute_dtype = dtype
+    B, L = args.batch, int(args.seconds * 16000)
+    g = torch.Generator(device=dev).manual_seed(rank)
+    wav = 0.1 * torch.randn(B, L, device=dev, generator=g)
+    gathered = torch.empty(world * B, model.embedding_size, device=dev) if world > 1 else None
+
+    def step():
+        _, emb = model(wav, is_eval=True)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, emb)
+        return emb
+
+    for _ in range(args.warmup):
+        step()
+    if not args.no_profile:
+        model.set_profile(True)
+        model.get_profile(reset=True)
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        emb = step()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    assert bool(torch.isfinite(emb).all()), "non-finite x-vectors"
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = t.item()
+
+    if rank == 0:
+        T = 1 + L // (160 if args.arch == "halfresnet34" else 512)
+        out = {
+            "metric": "x-vectors/sec (4 s @ 16 kHz)", "value": world * B * args.steps / dt, "unit": "x-vectors/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+            "config": {"workload": f"{'HalfResNet34' if args.arch == 'halfresnet34' else 'TDNN x-vector'} Xtractor.forward(is_eval=True), "
+                                   f"{dtype} trunk, batch={B} per GPU, synthetic {args.seconds:g} s @ 16 kHz (BASELINE.json configs[1])",
+                       "batch_per_gpu": B, "samples_per_utt": L, "frames_per_utt": T,
+                       "parallelism": f"utterance-sharded x{world}" + (" + RCCL all-gather of x-vectors" if world > 1 else "")},
+        }
+        if not args.no_profile:
+            prof = model.get_profile(reset=True)
+            r = roofline(prof, B, T, dtype) if args.arch == "halfresnet34" else None
+            if r is not None:
+                r["per_class_ms_per_step"] = {k: round(v[0] / args.steps, 4) for k, v in prof.items()}
+            out["roofline"] = r
+        if world == 1 and not args.no_cpu_baseline and args.arch == "halfresnet34":
+            out["cpu_baseline"] = cpu_baseline(args.seconds)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

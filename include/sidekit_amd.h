@@ -95,6 +95,19 @@ int xt_set_norm_embedding(xt_handle* h, int32_t on);
 int xt_set_debug(xt_handle* h, int32_t on);
 int xt_debug_tap(xt_handle* h, const char* name, void* h_dst, size_t capacity, size_t* bytes);
 
+/* Measurement: when on, every kernel launch of the forward is bracketed by HIP events recorded on
+ * the launch stream.  xt_get_profile synchronises and returns, per slot, the summed device time (ms)
+ * and the number of launches since the last reset.  Slots 0..10 are the 3x3 / 1x1 trunk convolution
+ * shapes in the order L1, L1-shortcut, L2a, L2-shortcut, L2, L3a, L3-shortcut, L3, L4a, L4-shortcut, L4. */
+#define XT_PROF_FRONTEND 11
+#define XT_PROF_STEM 12
+#define XT_PROF_SE_RES 13
+#define XT_PROF_POOL_TAIL 14
+#define XT_PROF_TDNN 15
+#define XT_PROF_SLOTS 16
+int xt_set_profile(xt_handle* h, int32_t on);
+int xt_get_profile(xt_handle* h, double* ms /*[XT_PROF_SLOTS]*/, int64_t* launches /*[XT_PROF_SLOTS]*/, int32_t reset);
+
 const char* xt_last_error(void);
 
 /* ---- trial scoring ------------------------------------------------------------------------- */

@@ -14,6 +14,9 @@ SK_OK, SK_EARG, SK_ESHAPE, SK_EHIP, SK_EWORKSPACE, SK_ESTATE = 0, -1, -2, -3, -4
 XT_ARCH_HALFRESNET34, XT_ARCH_TDNN = 0, 1
 XT_F32, XT_BF16, XT_F64, XT_I64 = 0, 1, 2, 3
 XT_LOSS_AAM, XT_LOSS_CCE = 0, 1
+XT_PROF_SLOTS = 16
+PROF_NAMES = ("conv_L1", "conv_L1S", "conv_L2A", "conv_L2S", "conv_L2", "conv_L3A", "conv_L3S", "conv_L3", "conv_L4A", "conv_L4S",
+              "conv_L4", "frontend", "stem", "se_residual", "pool_tail", "tdnn")
 
 
 class XtConfig(ctypes.Structure):
@@ -37,6 +40,8 @@ SIGNATURES = {
     "xt_forward_features": (ctypes.c_int, [_P, _P, _P, _I32, _I32, _P, _P, _P]),
     "xt_features": (ctypes.c_int, [_P, _P, _I64, _P, _I32, _I64, _P, _P]),
     "xt_set_norm_embedding": (ctypes.c_int, [_P, _I32]),
+    "xt_set_profile": (ctypes.c_int, [_P, _I32]),
+    "xt_get_profile": (ctypes.c_int, [_P, ctypes.POINTER(_F64), ctypes.POINTER(_I64), _I32]),
     "xt_set_debug": (ctypes.c_int, [_P, _I32]),
     "xt_debug_tap": (ctypes.c_int, [_P, ctypes.c_char_p, _P, _SZ, ctypes.POINTER(_SZ)]),
     "xt_last_error": (ctypes.c_char_p, []),

@@ -104,6 +104,13 @@ struct xt_handle {
   size_t ring_bytes = 0;
   int ring_cur = 0;
   bool norm_embedding = true;
+  // per-kernel-class HIP-event profile (xt_set_profile)
+  bool profile = false;
+  struct ProfRec { int slot; hipEvent_t a, b; };
+  std::vector<ProfRec> prof_recs;
+  std::vector<hipEvent_t> prof_pool;
+  double prof_ms[XT_PROF_SLOTS] = {0};
+  int64_t prof_n[XT_PROF_SLOTS] = {0};
   // debug taps
   bool debug = false;
   struct Tap { DevBuf buf; size_t bytes = 0; };
@@ -389,6 +396,22 @@ __global__ void rows_to_bft_kernel(const float* __restrict__ src, float* __restr
   }
 }
 
+// Brackets one launch with HIP events on the launch stream when profiling is on.
+struct ProfScope {
+  xt_handle* h; hipStream_t st; int slot; hipEvent_t a = nullptr, b = nullptr;
+  ProfScope(xt_handle* h_, int slot_, hipStream_t st_) : h(h_), st(st_), slot(slot_) {
+    if (!h->profile) return;
+    auto get = [&]() { hipEvent_t e; if (!h->prof_pool.empty()) { e = h->prof_pool.back(); h->prof_pool.pop_back(); } else (void)hipEventCreate(&e); return e; };
+    a = get(); b = get();
+    (void)hipEventRecord(a, st);
+  }
+  ~ProfScope() {
+    if (!a) return;
+    (void)hipEventRecord(b, st);
+    h->prof_recs.push_back({slot, a, b});
+  }
+};
+
 static int tap(xt_handle* h, const char* name, const void* src, size_t bytes, hipStream_t st) {
   if (!h->debug) return SK_OK;
   auto& t = h->taps[name];
@@ -443,7 +466,7 @@ static int frontend_rows(xt_handle* h, const float* d_wav, int64_t wav_ld, const
   g.preemph = 0.97f;
   g.W = h->d_basis; g.ldw = f.win; g.C = (float*)h->ws_S.p; g.ldc = 2 * h->nbp; g.M = M; g.N = 2 * h->nbp; g.K = f.win;
   SK_CHECK((size_t)M * 2 * h->nbp * 4 <= h->ws_S.bytes, SK_EWORKSPACE, "spectrum workspace too small (xt_reserve)");
-  SK_TRY(launch_gemm(g, st));
+  { ProfScope ps(h, XT_PROF_FRONTEND, st); SK_TRY(launch_gemm(g, st)); }
   // 2) |.|^2 x mel filterbank, log(. + 1e-6)
   GemmArgs p = gemm_args();
   p.a_mode = A_POWER; p.A = h->ws_S.p; p.lda = 2 * h->nbp; p.kc = h->nbp;
@@ -451,16 +474,16 @@ static int frontend_rows(xt_handle* h, const float* d_wav, int64_t wav_ld, const
   const bool mfcc = h->cfg.arch == XT_ARCH_TDNN;
   float* logmel = mfcc ? (float*)h->ws_act[3].p : d_feat_rows;
   p.C = logmel; p.ldc = f.n_mels;
-  SK_TRY(launch_gemm(p, st));
+  { ProfScope ps(h, XT_PROF_FRONTEND, st); SK_TRY(launch_gemm(p, st)); }
   if (mfcc) {  // 3) DCT-II (ortho) 100 -> 80
     GemmArgs d = gemm_args();
     d.a_mode = A_PLAIN; d.A = logmel; d.lda = f.n_mels; d.a_rows = M; d.W = h->d_dctT; d.ldw = f.n_mels;
     d.C = d_feat_rows; d.ldc = f.n_out; d.M = M; d.N = f.n_out; d.K = f.n_mels;
-    SK_TRY(launch_gemm(d, st));
+    { ProfScope ps(h, XT_PROF_FRONTEND, st); SK_TRY(launch_gemm(d, st)); }
   }
   // 4) CMVN over the utterance's own frames
   RowSpan rs{m.d_offsets, m.T, m.lens, 0, 0};
-  SK_TRY(launch_cmvn(d_feat_rows, f.n_out, f.n_out, rs, 1e-5f, m.B, st));
+  { ProfScope ps(h, XT_PROF_FRONTEND, st); SK_TRY(launch_cmvn(d_feat_rows, f.n_out, f.n_out, rs, 1e-5f, m.B, st)); }
   return SK_OK;
 }
 
@@ -493,7 +516,7 @@ static int half_from_feats(xt_handle* h, const float* feats, long sb, long sf, l
   const size_t act_bytes = (size_t)B * T * 80 * 32 * EB;
   for (int i = 0; i < 4; ++i) SK_CHECK(act_bytes <= h->ws_act[i].bytes, SK_EWORKSPACE, "activation workspace too small: call xt_reserve(%d, >= %d frames)", B, T);
   void *X = h->ws_act[0].p, *O1 = h->ws_act[1].p, *O2 = h->ws_act[2].p, *SC = h->ws_act[3].p;
-  SK_TRY(launch_stem(feats, sb, sf, stt, h->stem_w, h->stem_scale, h->stem_shift, X, dt, m.lens, B, T, st));
+  { ProfScope ps(h, XT_PROF_STEM, st); SK_TRY(launch_stem(feats, sb, sf, stt, h->stem_w, h->stem_scale, h->stem_shift, X, dt, m.lens, B, T, st)); }
   SK_TRY(tap(h, "stem", X, act_bytes, st));
   int prev_li = 0;
   for (size_t bi = 0; bi < h->blocks.size(); ++bi) {
@@ -506,22 +529,23 @@ static int half_from_feats(xt_handle* h, const float* feats, long sb, long sf, l
     // conv1 (+bn1 +relu)
     a.in = X; a.wpack = b.c1.wpack; a.scale = b.c1.scale; a.shift = b.c1.shift; a.out = O1; a.se_part = nullptr;
     a.halvings_in = lin; a.Hin = Hl[lin]; a.Hout = Hl[li]; a.relu = 1;
-    SK_TRY(launch_conv(b.c1.shape, dt, a, st));
+    { ProfScope ps(h, b.c1.shape, st); SK_TRY(launch_conv(b.c1.shape, dt, a, st)); }
     // conv2 (+bn2) with SE plane sums
     a.in = O1; a.wpack = b.c2.wpack; a.scale = b.c2.scale; a.shift = b.c2.shift; a.out = O2; a.se_part = (float*)h->ws_se.p;
     a.halvings_in = li; a.Hin = Hl[li]; a.Hout = Hl[li]; a.relu = 0;
-    SK_TRY(launch_conv(b.c2.shape, dt, a, st));
+    { ProfScope ps(h, b.c2.shape, st); SK_TRY(launch_conv(b.c2.shape, dt, a, st)); }
     const void* shortcut = X;
     if (first) {  // 1x1 conv (stride s) + bn on the block input
       a.in = X; a.wpack = b.sc.wpack; a.scale = b.sc.scale; a.shift = b.sc.shift; a.out = SC; a.se_part = nullptr;
       a.halvings_in = lin; a.Hin = Hl[lin]; a.Hout = Hl[li]; a.relu = 0;
-      SK_TRY(launch_conv(b.sc.shape, dt, a, st));
+      { ProfScope ps(h, b.sc.shape, st); SK_TRY(launch_conv(b.sc.shape, dt, a, st)); }
       shortcut = SC;
     }
     const int wout = 80 >> li;
-    SK_TRY(launch_se_gate((const float*)h->ws_se.p, cdiv(Hl[li], b.c2.g.th), b.c2.g.wm, b.c2.g.th, b.se_w1, b.se_w2,
-                          (float*)h->ws_gate.p, m.lens, li, wout, b.C, B, st));
-    SK_TRY(launch_residual(O2, (const float*)h->ws_gate.p, shortcut, O1, dt, B, (long)Hl[li] * wout, b.C, st));
+    { ProfScope ps(h, XT_PROF_SE_RES, st);
+      SK_TRY(launch_se_gate((const float*)h->ws_se.p, cdiv(Hl[li], b.c2.g.th), b.c2.g.wm, b.c2.g.th, b.se_w1, b.se_w2,
+                            (float*)h->ws_gate.p, m.lens, li, wout, b.C, B, st));
+      SK_TRY(launch_residual(O2, (const float*)h->ws_gate.p, shortcut, O1, dt, B, (long)Hl[li] * wout, b.C, st)); }
     std::swap(X, O1);
     const bool last_of_layer = (bi + 1 == h->blocks.size()) || (h->blocks[bi + 1].li != li);
     if (last_of_layer) {
@@ -535,6 +559,7 @@ static int half_from_feats(xt_handle* h, const float* feats, long sb, long sf, l
   const int H4 = Hl[3], D = 2560, R = B * H4;
   const int xbf = dt == DT_BF16;
   RowSpan rs{nullptr, H4, m.lens, 3, 0};
+  ProfScope ps_pool(h, XT_PROF_POOL_TAIL, st);
   SK_TRY(launch_mean_std(X, xbf, D, D, rs, (float*)h->ws_ctx.p, B, st));
   GemmArgs c = gemm_args();  // context term of attention.0: W1[:, 2560:] . [mean | std] + bias, once per utterance
   c.A = h->ws_ctx.p; c.lda = 2 * D; c.a_rows = B; c.W = h->att_w1c; c.ldw = 2 * D; c.C = (float*)h->ws_rb.p; c.ldc = 128;
@@ -572,11 +597,12 @@ static int tdnn_from_rows(xt_handle* h, const float* rows, const BatchMeta& m, f
     g.A = in; g.lda = lda; g.a_rows = R; g.kc = L.k > 1 ? L.cin : 0; g.dil = L.dil;
     g.W = L.w; g.ldw = (long)L.cin * L.k; g.C = out; g.ldc = L.cout; g.M = R; g.N = L.cout; g.K = L.cin * L.k;
     g.bias = L.bias; g.act = ACT_LRELU02; g.scale = L.scale; g.shift = L.shift;  // conv -> LeakyReLU(0.2) -> BatchNorm1d
-    SK_TRY(launch_gemm(g, st));
+    { ProfScope ps(h, XT_PROF_TDNN, st); SK_TRY(launch_gemm(g, st)); }
     const std::string nm = "conv" + std::to_string(i + 1);
     SK_TRY(tap(h, nm.c_str(), out, (size_t)R * L.cout * 4, st));
     in = out; lda = L.cout;
   }
+  ProfScope ps_pool(h, XT_PROF_POOL_TAIL, st);
   RowSpan rs{m.d_offsets, 0, m.lens, 0, 14};  // context_size()-1 = 4 + 4 + 6 frames consumed by the valid convs
   SK_TRY(launch_mean_std(in, 0, 1536, 1536, rs, (float*)h->ws_pooled.p, m.B, st));
   SK_TRY(tap(h, "pooled", h->ws_pooled.p, (size_t)m.B * 3072 * 4, st));
@@ -674,6 +700,8 @@ int xt_destroy(xt_handle* h) {
                     &h->ws_ctx, &h->ws_rb, &h->ws_h, &h->ws_e, &h->ws_pooled, &h->ws_pre, &h->ws_emb, &h->ws_int, &h->ws_ragged};
   for (DevBuf* b : bufs) b->release();
   for (auto& kv : h->taps) kv.second.buf.release();
+  for (auto& r : h->prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+  for (auto e : h->prof_pool) (void)hipEventDestroy(e);
   for (int i = 0; i < xt_handle::RING; ++i)
     if (h->ring_host[i]) { (void)hipHostFree(h->ring_host[i]); (void)hipEventDestroy(h->ring_ev[i]); }
   delete h;
@@ -828,6 +856,29 @@ int xt_features(xt_handle* h, const float* d_wav, int64_t wav_ld, const int32_t*
 int xt_set_norm_embedding(xt_handle* h, int32_t on) {
   SK_CHECK(h, SK_EARG, "null handle");
   h->norm_embedding = on != 0;
+  return SK_OK;
+}
+
+int xt_set_profile(xt_handle* h, int32_t on) {
+  SK_CHECK(h, SK_EARG, "null handle");
+  h->profile = on != 0;
+  return SK_OK;
+}
+
+int xt_get_profile(xt_handle* h, double* ms, int64_t* launches, int32_t reset) {
+  SK_CHECK(h && ms && launches, SK_EARG, "xt_get_profile: null argument");
+  SK_HIP(hipSetDevice(h->device));
+  for (auto& r : h->prof_recs) {
+    SK_HIP(hipEventSynchronize(r.b));
+    float t = 0.f;
+    SK_HIP(hipEventElapsedTime(&t, r.a, r.b));
+    h->prof_ms[r.slot] += t;
+    h->prof_n[r.slot] += 1;
+    h->prof_pool.push_back(r.a); h->prof_pool.push_back(r.b);
+  }
+  h->prof_recs.clear();
+  for (int i = 0; i < XT_PROF_SLOTS; ++i) { ms[i] = h->prof_ms[i]; launches[i] = h->prof_n[i]; }
+  if (reset) for (int i = 0; i < XT_PROF_SLOTS; ++i) { h->prof_ms[i] = 0; h->prof_n[i] = 0; }
   return SK_OK;
 }
 

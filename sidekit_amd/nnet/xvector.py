@@ -193,6 +193,17 @@ class Xtractor:
             out[n] = buf
         return out
 
+    def set_profile(self, on, dtype=None):
+        """Bracket every kernel launch of ``forward`` with HIP events on the launch stream (measurement only)."""
+        _lib.check(_lib.lib().xt_set_profile(self._handle(dtype), 1 if on else 0))
+
+    def get_profile(self, dtype=None, reset=True):
+        """``{kernel class: (device ms, launches)}`` accumulated since the last reset."""
+        ms = (ctypes.c_double * _lib.XT_PROF_SLOTS)()
+        n = (ctypes.c_int64 * _lib.XT_PROF_SLOTS)()
+        _lib.check(_lib.lib().xt_get_profile(self._handle(dtype), ms, n, 1 if reset else 0))
+        return {name: (ms[i], n[i]) for i, name in enumerate(_lib.PROF_NAMES) if n[i]}
+
     def set_debug(self, on, dtype=None):
         _lib.check(_lib.lib().xt_set_debug(self._handle(dtype), 1 if on else 0))
 
