@@ -128,6 +128,17 @@ int sc_plda_fast(const double* d_E, int32_t Ne, const double* d_T, int32_t Nt, i
 int sc_cosine_trials(const float* d_E, const float* d_T, int32_t D, const int32_t* d_enr_idx, const int32_t* d_tst_idx,
                      int64_t n_trials, double* d_out, void* stream);
 
+/* ---- EER support (host code, no GPU needed) --------------------------------------------------- */
+
+/* sidekit.bosaris.detplot.pavx (sidekit/bosaris/detplot.py:289-351): isotonic (non-decreasing) fit of y.
+ * width / height need room for n entries; *nbins receives the number of bins.  ghat_out (n) may be NULL. */
+int sk_pavx(const double* y, int64_t n, double* ghat_out, int64_t* width, double* height, int64_t* nbins);
+
+/* Vertex walk of sidekit.bosaris.detplot.rocch (detplot.py:414-434): pideal is the 1/0 target indicator
+ * ordered by ascending score (stable sort), width the PAV bins; pmiss / pfa receive nbins + 1 vertices. */
+int sk_rocch_vertices(const double* pideal, int64_t n, int64_t n_tar, int64_t n_non, const int64_t* width, int64_t nbins,
+                      double* pmiss, double* pfa);
+
 #ifdef __cplusplus
 }
 #endif

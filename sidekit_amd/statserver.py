@@ -1,0 +1,143 @@
+"""``StatServer`` -- the container the scoring functions exchange (subset of ``sidekit/statserver.py``).
+
+Mirrors the attributes (``modelset, segset, start, stop, stat0, stat1``; ``statserver.py:202-231``) and
+the ~10 methods the x-vector scoring path calls: ``validate`` (:318-336), ``align_models`` /
+``align_segments`` (:656-684), ``norm_stat1`` / ``rotate_stat1`` / ``center_stat1`` / ``whiten_stat1``
+(:797-817,852-896), ``get_mean_stat1`` (:789-795), ``mean_stat_per_model`` (:1357-1374).  GMM statistics,
+MAP, i-vector extraction and HDF5 I/O are out of scope.  Values are float64
+(``STAT_TYPE``, ``sidekit/__init__.py:59``); the alignments use hashed lookups instead of per-id scans.
+"""
+import copy
+import logging
+
+import numpy
+import scipy.linalg
+
+from .bosaris import IdMap
+from .bosaris._sets import first_index
+
+STAT_TYPE = numpy.float64
+
+
+class StatServer:
+    def __init__(self, statserver_file_name=None, distrib_nb=0, feature_size=0, index=None, ubm=None):
+        self.modelset = numpy.empty(0, dtype="|O")
+        self.segset = numpy.empty(0, dtype="|O")
+        self.start = numpy.empty(0, dtype="|O")
+        self.stop = numpy.empty(0, dtype="|O")
+        self.stat0 = numpy.array([], dtype=STAT_TYPE)
+        self.stat1 = numpy.array([], dtype=STAT_TYPE)
+        if statserver_file_name is None:
+            return
+        if isinstance(statserver_file_name, IdMap):
+            im = statserver_file_name
+            self.modelset, self.segset, self.start, self.stop = im.leftids, im.rightids, im.start, im.stop
+            self.stat0 = numpy.zeros((self.segset.shape[0], distrib_nb), dtype=STAT_TYPE)
+            self.stat1 = numpy.zeros((self.segset.shape[0], distrib_nb * feature_size), dtype=STAT_TYPE)
+            return
+        raise NotImplementedError("reading a StatServer from an HDF5 file is out of scope (SURVEY 8f rank 3)")
+
+    def __repr__(self):
+        line = '-' * 30 + '\n'
+        return (line + 'modelset: ' + repr(self.modelset) + '\nsegset: ' + repr(self.segset) + '\nseg start:' + repr(self.start)
+                + '\nseg stop:' + repr(self.stop) + '\nstat0:' + repr(self.stat0) + '\nstat1:' + repr(self.stat1) + '\n' + line)
+
+    def validate(self, warn=False):
+        ok = self.modelset.ndim == 1 \
+            and (self.modelset.shape == self.segset.shape == self.start.shape == self.stop.shape) \
+            and (self.stat0.shape[0] == self.stat1.shape[0] == self.modelset.shape[0]) \
+            and (not bool(self.stat1.shape[1] % self.stat0.shape[1]))
+        if warn and (self.segset.shape != numpy.unique(self.segset).shape):
+            logging.warning('Duplicated segments in StatServer')
+        return ok
+
+    def _take(self, indx):
+        self.segset = self.segset[indx]
+        self.modelset = self.modelset[indx]
+        self.start = self.start[indx]
+        self.stop = self.stop[indx]
+        self.stat0 = self.stat0[indx, :]
+        self.stat1 = self.stat1[indx, :]
+
+    def align_segments(self, segment_list):
+        """Reorder / reduce the sessions to match ``segment_list`` (first occurrence of each id)."""
+        self._take(first_index(self.segset, segment_list))
+
+    def align_models(self, model_list):
+        """Reorder / reduce the sessions to match ``model_list`` (first occurrence of each id)."""
+        self._take(first_index(self.modelset, model_list))
+
+    def get_model_stat0(self, mod_id):
+        return self.stat0[self.modelset == mod_id, :]
+
+    def get_model_stat1(self, mod_id):
+        return self.stat1[self.modelset == mod_id, :]
+
+    def get_segment_stat1(self, seg_id):
+        return self.stat1[self.segset == seg_id, :]
+
+    def get_mean_stat1(self):
+        return numpy.mean(self.stat1, axis=0)
+
+    def get_total_covariance_stat1(self):
+        c = self.stat1 - self.stat1.mean(axis=0)
+        return numpy.dot(c.transpose(), c) / self.stat1.shape[0]
+
+    def norm_stat1(self):
+        """Divide every first-order statistic by its Euclidean norm (clipped at 1e-8)."""
+        vect_norm = numpy.clip(numpy.linalg.norm(self.stat1, axis=1), 1e-08, numpy.inf)
+        self.stat1 = (self.stat1.transpose() / vect_norm).transpose()
+
+    def rotate_stat1(self, R):
+        self.stat1 = numpy.dot(self.stat1, R)
+
+    def center_stat1(self, mu):
+        dim = self.stat1.shape[1] // self.stat0.shape[1]
+        index_map = numpy.repeat(numpy.arange(self.stat0.shape[1]), dim)
+        self.stat1 = self.stat1 - (self.stat0[:, index_map] * mu.astype(STAT_TYPE))
+
+    def whiten_stat1(self, mu, sigma, isSqrInvSigma=False):
+        """Centre on ``mu`` then whiten with a diagonal (1-D) or full (2-D) covariance."""
+        if sigma.ndim == 1:
+            self.center_stat1(mu)
+            self.stat1 = self.stat1 / numpy.sqrt(sigma.astype(STAT_TYPE))
+        elif sigma.ndim == 2:
+            sqr_inv_sigma = sigma
+            if not isSqrInvSigma:
+                eigen_values, eigen_vectors = scipy.linalg.eigh(sigma)
+                ind = eigen_values.real.argsort()[::-1]
+                eigen_values = eigen_values.real[ind]
+                eigen_vectors = eigen_vectors.real[:, ind]
+                sqr_inv_sigma = numpy.dot(eigen_vectors, numpy.diag(1 / numpy.sqrt(eigen_values.real)))
+            self.center_stat1(mu)
+            self.rotate_stat1(sqr_inv_sigma)
+        else:
+            raise Exception('Wrong dimension of Sigma, must be 1 or 2')
+
+    def mean_stat_per_model(self):
+        """Average the statistics of the sessions sharing a model id -> one session per (sorted) model."""
+        out = StatServer()
+        out.modelset, inverse = numpy.unique(self.modelset, return_inverse=True)
+        out.segset = copy.deepcopy(out.modelset)
+        out.start = numpy.empty(out.segset.shape, '|O')
+        out.stop = numpy.empty(out.segset.shape, '|O')
+        out.stat0 = numpy.zeros((out.modelset.shape[0], self.stat0.shape[1]), dtype=STAT_TYPE)
+        out.stat1 = numpy.zeros((out.modelset.shape[0], self.stat1.shape[1]), dtype=STAT_TYPE)
+        for idx in range(out.modelset.shape[0]):
+            sel = inverse == idx
+            out.stat0[idx, :] = self.stat0[sel, :].mean(axis=0)
+            out.stat1[idx, :] = self.stat1[sel, :].mean(axis=0)
+        return out
+
+    @staticmethod
+    def from_arrays(modelset, segset, stat1, start=None, stop=None):
+        """Convenience used by ``extract_embeddings``: x-vectors as ``stat1``, ones as ``stat0`` (xvector.py:1905-1914)."""
+        s = StatServer()
+        s.modelset = numpy.asarray(modelset)
+        s.segset = numpy.asarray(segset)
+        n = s.segset.shape[0]
+        s.start = numpy.empty(n, dtype="|O") if start is None else numpy.asarray(start)
+        s.stop = numpy.empty(n, dtype="|O") if stop is None else numpy.asarray(stop)
+        s.stat0 = numpy.ones((n, 1), dtype=STAT_TYPE)
+        s.stat1 = numpy.asarray(stat1, dtype=STAT_TYPE)
+        return s

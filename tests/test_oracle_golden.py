@@ -1,0 +1,142 @@
+"""The oracle against the golden fixtures made with the imported reference (tests/golden/make_golden.py)."""
+import os
+
+import numpy
+import pytest
+import torch
+
+from oracle import frontend as ofe
+from oracle import scoring as osc
+from oracle import xvector as oxv
+from sidekit_amd.nnet.weights import seeded_state_dict
+
+
+def _feats(shape, seed):
+    g = torch.Generator().manual_seed(int(seed))
+    return torch.randn(*[int(s) for s in shape], generator=g)
+
+
+def _rel(a, b):
+    a, b = numpy.asarray(a, dtype=numpy.float64).ravel(), numpy.asarray(b, dtype=numpy.float64).ravel()
+    return numpy.linalg.norm(a - b) / numpy.linalg.norm(b)
+
+
+def _digest(t):
+    a = t.detach().double().flatten()
+    idx = torch.linspace(0, a.numel() - 1, 257).long()
+    return numpy.concatenate([[a.mean().item(), a.abs().mean().item(), a.pow(2).mean().sqrt().item(), a.max().item(), a.min().item()],
+                              a[idx].numpy()])
+
+
+@pytest.fixture(scope="module")
+def half(golden_dir):
+    fx = numpy.load(os.path.join(golden_dir, "halfresnet34.npz"))
+    return fx, seeded_state_dict("halfresnet34", int(fx["n_spk"]), seed=int(fx["seed"]))
+
+
+@pytest.mark.parametrize("tag", ["small", "odd", "len4s"])
+def test_halfresnet_oracle_matches_reference(half, tag):
+    fx, sd = half
+    feats = _feats(fx[f"{tag}_shape"], fx[f"{tag}_feat_seed"])
+    taps = {}
+    with torch.no_grad():
+        logits, emb = oxv.halfresnet34_from_feats(feats, sd, taps=taps)
+    for k in ("stem", "layer1", "layer2", "layer3"):
+        numpy.testing.assert_allclose(_digest(taps[k]), fx[f"{tag}_{k}_digest"], rtol=5e-4, atol=5e-4)
+    # fp32 noise floor of two different conv algorithms over 34 layers: norm-wise 1e-5 (the parity budget is 1e-4)
+    assert _rel(taps["layer4"].numpy(), fx[f"{tag}_layer4"]) < 1e-5
+    assert _rel(taps["pooled"].numpy(), fx[f"{tag}_pooled"]) < 1e-5
+    numpy.testing.assert_allclose(emb.numpy(), fx[f"{tag}_emb"], atol=2e-6)
+    numpy.testing.assert_allclose(logits.numpy(), fx[f"{tag}_logits"], atol=2e-4)
+    assert numpy.allclose(numpy.linalg.norm(emb.numpy(), axis=1), 1.0, atol=1e-6)
+
+
+def test_halfresnet_oracle_wav_fixture(half):
+    fx, sd = half
+    x = torch.from_numpy(fx["wav_pcm16"].astype(numpy.float32) / 32768.0)
+    with torch.no_grad():
+        _, emb = oxv.halfresnet34_forward(x, sd)
+        feats = ofe.melspec_frontend(x)
+    # fixture side: reference PreEmphasis (conv1d) + InstanceNorm1d around the stand-in mel; log(mel + 1e-6) of
+    # near-silent bins amplifies the last-bit differences of the two pre-emphasis forms
+    assert _rel(feats.numpy(), fx["wav_feats_unpinned_frontend"]) < 2e-5
+    assert _rel(emb.numpy(), fx["wav_emb_unpinned_frontend"]) < 2e-5
+
+
+def test_tdnn_oracle_matches_reference(golden_dir):
+    fx = numpy.load(os.path.join(golden_dir, "tdnn.npz"))
+    for loss in ("aam", "cce"):
+        sd = seeded_state_dict("xvector", int(fx["n_spk"]), loss=loss, seed=int(fx["seed"]))
+        for tag in ("t63", "t126"):
+            feats = _feats(fx[f"{loss}_{tag}_shape"], fx[f"{loss}_{tag}_feat_seed"])
+            taps = {}
+            with torch.no_grad():
+                out = oxv.tdnn_from_feats(feats, sd, loss, taps=taps)
+            if loss == "aam":
+                numpy.testing.assert_allclose(_digest(taps["conv5"]), fx[f"{tag}_conv5_digest"], rtol=5e-4, atol=5e-4)
+                numpy.testing.assert_allclose(taps["pooled"].numpy(), fx[f"{tag}_pooled"], rtol=1e-5, atol=1e-5)
+                numpy.testing.assert_allclose(out[0].numpy(), fx[f"aam_{tag}_logits"], atol=3e-4)
+                numpy.testing.assert_allclose(out[1].numpy(), fx[f"aam_{tag}_emb"], atol=2e-6)
+            else:
+                numpy.testing.assert_allclose(out.numpy(), fx[f"cce_{tag}_emb"], atol=2e-6)
+
+
+def _aligned(fx):
+    em = {m: i for i, m in enumerate(fx["enr_ids"])}
+    tm = {s: i for i, s in enumerate(fx["tst_ids"])}
+    return fx["E"][[em[m] for m in fx["cos_modelset"]]], fx["T"][[tm[s] for s in fx["cos_segset"]]]
+
+
+def test_scoring_oracle_matches_reference(golden_dir):
+    fx = numpy.load(os.path.join(golden_dir, "scoring.npz"))
+    Ea, Ta = _aligned(fx)
+    numpy.testing.assert_allclose(osc.cosine_scores(Ea, Ta), fx["cos_scoremat"], atol=1e-6)
+    numpy.testing.assert_allclose(osc.cosine_scores(Ea.dot(fx["wccn"]), Ta.dot(fx["wccn"])), fx["cos_wccn_scoremat"], atol=1e-6)
+    mu, F, G, Sigma = fx["mu"], fx["F"], fx["G"], fx["Sigma"]
+    numpy.testing.assert_allclose(osc.fast_plda_scores(Ea, Ta, mu, F, Sigma), fx["plda_scoremat"], rtol=1e-9, atol=1e-9)
+    numpy.testing.assert_allclose(osc.fast_plda_scores(Ea, Ta, mu, F, Sigma, scaling_factor=0.7), fx["plda_scaled_scoremat"], rtol=1e-9, atol=1e-9)
+    numpy.testing.assert_allclose(osc.fast_plda_scores(Ea, Ta, mu, F, Sigma, p_known=0.3), fx["plda_open_scoremat"], rtol=1e-9, atol=1e-9)
+    numpy.testing.assert_allclose(osc.full_plda_scores(Ea, Ta, mu, F, G, Sigma), fx["plda_full_scoremat"], rtol=1e-9, atol=1e-9)
+    numpy.testing.assert_allclose(osc.full_plda_scores(Ea, Ta, mu, F, G, Sigma, p_known=0.2, scaling_factor=0.9),
+                                  fx["plda_full_open_scoremat"], rtol=1e-9, atol=1e-9)
+    numpy.testing.assert_allclose(osc.norm_rows(fx["E"]), fx["norm_stat1"], rtol=0, atol=0)
+
+
+def test_rocch_oracle_matches_reference(golden_dir):
+    fx = numpy.load(os.path.join(golden_dir, "scoring.npz"))
+    pm, pf = osc.rocch(fx["rocch_tar"], fx["rocch_non"])
+    assert numpy.array_equal(pm, fx["rocch_pmiss"]) and numpy.array_equal(pf, fx["rocch_pfa"])
+    assert osc.rocch2eer(pm, pf) == float(fx["rocch_eer"])
+    g, w, h = osc.pavx(fx["pav_y"])
+    assert numpy.array_equal(g, fx["pav_ghat"]) and numpy.array_equal(w, fx["pav_width"]) and numpy.array_equal(h, fx["pav_height"])
+    assert osc.eer(fx["cos_tar"], fx["cos_non"]) == float(fx["cos_eer"])
+
+
+def test_frontend_stft_against_direct_dft():
+    """torch.stft path of the oracle vs an independent float64 direct DFT (torchaudio semantics are unpinned)."""
+    torch.manual_seed(3)
+    x = 0.1 * torch.randn(2, 4000)
+    y = ofe.pre_emphasis(x)
+    a = ofe.stft_power(y.double(), 1024, 160, 400).numpy()
+    b = ofe.stft_power_dft(y.numpy(), 1024, 160, 400)
+    numpy.testing.assert_allclose(a, b, rtol=1e-9, atol=1e-12)
+    a2 = ofe.stft_power(y.double(), 2048, 512, 1024).numpy()
+    b2 = ofe.stft_power_dft(y.numpy(), 2048, 512, 1024)
+    numpy.testing.assert_allclose(a2, b2, rtol=1e-9, atol=1e-12)
+    assert a.shape == (2, 513, 26) and a2.shape == (2, 1025, 8)
+
+
+def test_frontend_building_blocks():
+    x = torch.tensor([[1.0, 2.0, 4.0, 8.0]])
+    numpy.testing.assert_allclose(ofe.pre_emphasis(x).numpy(), [[1 - 0.97 * 2, 2 - 0.97, 4 - 0.97 * 2, 8 - 0.97 * 4]], rtol=1e-6)
+    fb = ofe.mel_filterbank(513, 90, 7600, 80, 16000)
+    assert fb.shape == (513, 80) and float(fb.min()) == 0.0 and float(fb.max()) <= 1.0
+    assert (fb.sum(0) > 0).all()                       # every mel band sees at least one bin
+    assert float(fb[:3].sum()) == 0.0                  # below f_min = 90 Hz (bins 0..2 = 0..31 Hz)
+    d = ofe.dct_matrix(80, 100)
+    numpy.testing.assert_allclose((d.t() @ d).numpy(), numpy.eye(80), atol=1e-5)   # orthonormal rows
+    f = ofe.cmvn(torch.randn(2, 80, 50) * 3 + 1)
+    assert abs(float(f.mean())) < 1e-6 and abs(float(f.var(dim=2, unbiased=False).mean()) - 1) < 1e-3
+    # N4: CMVN makes the features invariant to input gain
+    w = 0.1 * torch.randn(1, 3000)
+    numpy.testing.assert_allclose(ofe.melspec_frontend(w).numpy(), ofe.melspec_frontend(0.5 * w).numpy(), atol=2e-3)
