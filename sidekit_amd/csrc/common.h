@@ -55,6 +55,8 @@ __host__ __device__ inline uint16_t f32_to_bf16(float f) {
   if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
   return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
 }
+// ReLU that lets NaN through like torch.relu (fmaxf would swallow it)
+__device__ inline float relu_nan(float x) { return x < 0.f ? 0.f : x; }
 __device__ inline uint32_t pack_bf16x2(float lo, float hi) {
   return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
 }

@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           float x = acc[i][j][4 * g + q] * sc[g][q] + sh[g][q];
-          if (a.relu) x = fmaxf(x, 0.f);
+          if (a.relu) x = relu_nan(x);
           v[q] = x;
           ssum[4 * g + q] += valid ? x : 0.f;
         }

@@ -126,9 +126,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     float v = acc[q] + bias;
     if (g.rowbias) v += g.rowbias[(long)(m / g.rows_per_group) * g.N + n];
     switch (g.act) {
-      case ACT_RELU: v = fmaxf(v, 0.f); break;
+      case ACT_RELU: v = relu_nan(v); break;
       case ACT_LRELU02: v = v > 0.f ? v : 0.2f * v; break;
-      case ACT_RELU_BN_TANH: v = tanhf(fmaxf(v, 0.f) * sc + sh); break;
+      case ACT_RELU_BN_TANH: v = tanhf(relu_nan(v) * sc + sh); break;
       case ACT_LOG_EPS: v = logf(v + 1e-6f); break;
       default: break;
     }

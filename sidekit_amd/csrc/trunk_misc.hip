@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ fea
         float s = 0.f;
 #pragma unroll
         for (int q = 0; q < 9; ++q) s = fmaf(ws[(c0 + c) * 9 + q], x[q], s);
-        v[c] = fmaxf(s * ws[288 + c0 + c] + ws[320 + c0 + c], 0.f);
+        v[c] = relu_nan(s * ws[288 + c0 + c] + ws[320 + c0 + c]);
       }
       if constexpr (EB == 2) {
         *reinterpret_cast<uint4*>(op + c0 * 2) =
@@ -95,7 +95,7 @@ __global__ void se_gate_kernel(const float* __restrict__ se_part, int tiles, int
   if (c < R) {
     float a = 0.f;
     for (int k = 0; k < C; ++k) a = fmaf(w1[c * C + k], y[k], a);
-    hid[c] = fmaxf(a, 0.f);
+    hid[c] = relu_nan(a);
   }
   __syncthreads();
   float z = 0.f;
@@ -129,18 +129,18 @@ __global__ __launch_bounds__(256) void residual_kernel(const uint4* __restrict__
       uint32_t rv[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const float lo = fmaxf(bf16_to_f32(av[q] & 0xffff) * g[2 * q] + bf16_to_f32(sv[q] & 0xffff), 0.f);
-        const float hi = fmaxf(bf16_to_f32(av[q] >> 16) * g[2 * q + 1] + bf16_to_f32(sv[q] >> 16), 0.f);
+        const float lo = relu_nan(bf16_to_f32(av[q] & 0xffff) * g[2 * q] + bf16_to_f32(sv[q] & 0xffff));
+        const float hi = relu_nan(bf16_to_f32(av[q] >> 16) * g[2 * q + 1] + bf16_to_f32(sv[q] >> 16));
         rv[q] = pack_bf16x2(lo, hi);
       }
       r = make_uint4(rv[0], rv[1], rv[2], rv[3]);
     } else {
       const float4 af = __builtin_bit_cast(float4, a), sf = __builtin_bit_cast(float4, s);
       float4 rf;
-      rf.x = fmaxf(af.x * g[0] + sf.x, 0.f);
-      rf.y = fmaxf(af.y * g[1] + sf.y, 0.f);
-      rf.z = fmaxf(af.z * g[2] + sf.z, 0.f);
-      rf.w = fmaxf(af.w * g[3] + sf.w, 0.f);
+      rf.x = relu_nan(af.x * g[0] + sf.x);
+      rf.y = relu_nan(af.y * g[1] + sf.y);
+      rf.z = relu_nan(af.z * g[2] + sf.z);
+      rf.w = relu_nan(af.w * g[3] + sf.w);
       r = __builtin_bit_cast(uint4, rf);
     }
     y[i] = r;

@@ -1,0 +1,88 @@
+"""BASELINE.json's full sizes, checked through size-independent properties (the oracle would take minutes)."""
+import numpy
+import pytest
+import torch
+
+from oracle import xvector as oxv
+from sidekit_amd.bosaris import rocch, rocch2eer
+from sidekit_amd.nnet import Xtractor
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a, b = torch.as_tensor(a).double().flatten().cpu(), torch.as_tensor(b).double().flatten().cpu()
+    return ((a - b).norm() / b.norm()).item()
+
+
+@pytest.fixture(scope="module")
+def model(gpu):
+    return Xtractor(7205, model_archi="halfresnet34", loss="aam", seed=1234).to(gpu).eval()
+
+
+def test_config2_batch256_4s(model):
+    """HalfResNet34, batch 256, 4 s: unit norm, batch permutation equivariance, gain invariance, spot-check vs oracle."""
+    g = torch.Generator(device="cuda").manual_seed(0)
+    wav = 0.1 * torch.randn(256, 64000, device="cuda", generator=g)
+    for dtype in ("fp32", "bf16"):
+        model.compute_dtype = dtype
+        logits, emb = model(wav, is_eval=True)
+        assert emb.shape == (256, 256) and logits.shape == (256, 7205)
+        assert torch.allclose(emb.norm(dim=1), torch.ones(256, device="cuda"), atol=1e-5)
+        assert float(logits.abs().max()) <= 30.0 + 1e-3                        # s * cosine
+        perm = torch.randperm(256, device="cuda", generator=g)
+        _, emb_p = model(wav[perm], is_eval=True)
+        assert torch.equal(emb_p, emb[perm])                                   # utterances are independent
+        _, emb_g = model(0.25 * wav[:8], is_eval=True)                         # N4: gain invariance through CMVN
+        assert float(torch.nn.functional.cosine_similarity(emb_g, emb[:8]).min()) > (0.9999 if dtype == "fp32" else 0.995)
+    model.compute_dtype = "fp32"
+    _, emb = model(wav, is_eval=True)
+    with torch.no_grad():
+        _, ref = oxv.halfresnet34_forward(wav[[3, 200]].cpu(), model.state_dict())
+    assert rel(emb[[3, 200]], ref) < 1e-4
+
+
+def test_bf16_deviation_does_not_move_the_eer(model):
+    """bf16 is judged by EER.  No trained checkpoint or dataset exists offline and a random-weight
+    network maps every input to nearly the same direction (cosine 0.995 between any two), so the EER check is
+    compositional: the MEASURED bf16-vs-fp32 deviation vectors of 256 real forward passes are added to the
+    BASELINE config-5 synthetic speaker embeddings (250 speakers, EER ~ 2.9 %) and the 1M-trial cosine EER must
+    move by <= 0.05 % absolute."""
+    g = torch.Generator(device="cuda").manual_seed(11)
+    wav = 0.1 * torch.randn(256, 32000, device="cuda", generator=g)
+    model.compute_dtype = "fp32"
+    _, e32 = model(wav, is_eval=True)
+    model.compute_dtype = "bf16"
+    _, e16 = model(wav, is_eval=True)
+    model.compute_dtype = None
+    delta = (e16 - e32).double().cpu().numpy()                    # per-utterance deviation, ||e32|| = 1
+    dn = numpy.linalg.norm(delta, axis=1)
+    assert 1e-4 < dn.mean() < 3e-2, dn.mean()
+    rs = numpy.random.RandomState(0)
+    n_spk, D, Ne, Nt = 250, 256, 1000, 1000
+    c = rs.randn(n_spk, D)
+    spk_e, spk_t = rs.randint(0, n_spk, Ne), rs.randint(0, n_spk, Nt)
+    norm = lambda x: x / numpy.linalg.norm(x, axis=1, keepdims=True)
+    E, T = norm(c[spk_e] + 1.8 * rs.randn(Ne, D)), norm(c[spk_t] + 1.8 * rs.randn(Nt, D))
+    tar = spk_e[:, None] == spk_t[None, :]
+    E16, T16 = norm(E + delta[rs.randint(0, 256, Ne)]), norm(T + delta[rs.randint(0, 256, Nt)])
+    from sidekit_amd import iv_scoring
+    s32, s16 = iv_scoring.cosine_matrix(E, T), iv_scoring.cosine_matrix(E16, T16)
+    eer32 = rocch2eer(*rocch(s32[tar].astype(float), s32[~tar].astype(float)))
+    eer16 = rocch2eer(*rocch(s16[tar].astype(float), s16[~tar].astype(float)))
+    assert 0.01 < eer32 < 0.05 and abs(eer16 - eer32) <= 5e-4, (eer32, eer16)
+
+
+def test_config4_tdnn_512_variable_length(gpu):
+    """TDNN fp32, 512 utterances of 2-10 s (RandomState(0) lengths): finite unit-norm output, spot parity vs the oracle."""
+    m = Xtractor(7205, model_archi="xvector", loss="aam", seed=4321).to(gpu).eval()
+    lens = numpy.random.RandomState(0).randint(32000, 160001, (512,))
+    g = torch.Generator(device="cuda").manual_seed(0)
+    wav = 0.1 * torch.randn(512, int(lens.max()), device="cuda", generator=g)
+    logits, emb = m(wav, is_eval=True, lengths=lens.tolist())
+    assert emb.shape == (512, 256) and bool(torch.isfinite(emb).all())
+    assert torch.allclose(emb.norm(dim=1), torch.ones(512, device="cuda"), atol=1e-5)
+    idx = [0, 17, 511, int(lens.argmin()), int(lens.argmax())]
+    with torch.no_grad():
+        _, ref = oxv.forward_ragged([wav[i, :lens[i]].cpu() for i in idx], m.state_dict(), arch="xvector")
+    assert rel(emb[idx], ref) < 1e-4
