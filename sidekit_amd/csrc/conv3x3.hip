@@ -45,7 +45,8 @@ struct ConvCfg {
   static constexpr int WP = WIN + 2;             // staged input columns (zero column each side)
   static constexpr int CB = CK * EB;             // channel bytes staged per position
   static constexpr int PSTRIDE = CB + 16;        // +16 B: ds_read_b128 of 32 neighbouring positions is conflict-free
-  static constexpr int LDS = RIN * WP * PSTRIDE;
+  static constexpr int NPOS = RIN * WP;
+  static constexpr int LDS = (NPOS * PSTRIDE + 1023) / 1024 * 1024;  // whole 1-KiB LDS-DMA pieces
   static constexpr int KS = CB / 32;             // MFMA k-steps (32 B of k) per tap per chunk
   static constexpr int NCH = CIN / CK;           // channel chunks
   static constexpr int KTOT = NCH * TAPS * KS;   // k-steps per output-channel tile
@@ -58,12 +59,16 @@ struct ConvCfg {
 template <class C>
 __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
   using T = typename C::T;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[C::LDS];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[C::LDS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
   const int wm = wave / C::WN, wn = wave % C::WN;
   const int tiles = (a.Hout + C::TH - 1) / C::TH;
-  const int b = blockIdx.x / tiles, tile = blockIdx.x % tiles;
+  // XCD-aware order: blocks are dealt round-robin over the 8 XCDs (bid % 8 shares an L2), so give every XCD a
+  // contiguous run of (utterance, row-tile) work items -> vertically adjacent tiles share their halo rows in L2
+  const int nblk = gridDim.x, q8 = nblk >> 3, r8 = nblk & 7, xcd = blockIdx.x & 7;
+  const int work = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
+  const int b = work / tiles, tile = work % tiles;
   const int ho0 = tile * C::TH;
   const int hin_b = halve(a.lens.get(b), a.halvings_in);
   const int hout_b = (C::S == 2) ? ((hin_b + 1) >> 1) : hin_b;
@@ -89,36 +94,62 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
   const unsigned char* in = reinterpret_cast<const unsigned char*>(a.in);
   const int hi0 = ho0 * C::S - 1;
 
+  // Weight fragments stream L2 -> VGPR through a small software ring: PD k-steps ahead of their use (all of a
+  // chunk's fragments when they fit), so the ~700-cycle L2 latency is paid once per chunk, under the staging DMA.
+  constexpr int NK = C::TAPS * C::KS;                                   // k-steps per channel chunk
+  constexpr int PD = (NK * C::NW <= 24) ? NK : (C::NW == 1 ? 8 : 4);    // prefetch depth in k-steps
   for (int ch = 0; ch < C::NCH; ++ch) {
+    uint4 wq[PD][C::NW];
+#pragma unroll
+    for (int d = 0; d < PD; ++d)
+#pragma unroll
+      for (int j = 0; j < C::NW; ++j) wq[d][j] = wp[((size_t)j * C::KTOT + ch * NK + d) * 64];
+    __builtin_amdgcn_sched_barrier(0);  // keep the loads up here: the scheduler otherwise sinks them next to their use
     if (ch) __syncthreads();
-    constexpr int CPP = C::CB / 16;
-    constexpr int NCHUNK = C::RIN * C::WP * CPP;
-    for (int idx = tid; idx < NCHUNK; idx += 256) {
-      const int pos = idx / CPP, cc = idx % CPP;
+    // stage the halo tile with LDS-DMA (global_load_lds_dwordx4: 64 lanes x 16 B land on 1 KiB of LDS, no VGPRs,
+    // every piece in flight at once).  A lane whose slot is a pad slot or a zero-padding position reads `zeros`.
+    constexpr int CPP = C::CB / 16, SPP = C::PSTRIDE / 16, NPIECE = C::LDS / 1024;
+#pragma unroll 2
+    for (int it = wave; it < NPIECE; it += 4) {
+      const int slot = it * 64 + lane;
+      const int pos = slot / SPP, cc = slot % SPP;
       const int row = pos / C::WP, col = pos % C::WP;
       const int hi = hi0 + row, wi = col - 1;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (hi >= 0 && hi < hin_b && wi >= 0 && wi < C::WIN)
-        v = *reinterpret_cast<const uint4*>(in + ((((size_t)b * a.Hin + hi) * C::WIN + wi) * C::CIN + ch * C::CK) * C::EB + cc * 16);
-      *reinterpret_cast<uint4*>(smem + pos * C::PSTRIDE + cc * 16) = v;
+      const unsigned char* src = reinterpret_cast<const unsigned char*>(a.zeros);
+      if (cc < CPP && pos < C::NPOS && hi >= 0 && hi < hin_b && wi >= 0 && wi < C::WIN)
+        src = in + ((((size_t)b * a.Hin + hi) * C::WIN + wi) * C::CIN + ch * C::CK) * C::EB + cc * 16;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(smem + it * 1024), 16, 0, 0);
     }
     __syncthreads();
-#pragma unroll
-    for (int t = 0; t < C::TAPS; ++t) {
+    auto xaddr = [&](int i, int kk) {
+      const int t = kk / C::KS, ks = kk % C::KS;
       const int tap = (C::TAPS == 9) ? t : 4;
-      const int toff = ((tap / 3) * C::WP + tap % 3) * C::PSTRIDE;
+      return smem + base[i] + ((tap / 3) * C::WP + tap % 3) * C::PSTRIDE + ks * 32;
+    };
+    uint4 xc[C::MW], xn[C::MW];
 #pragma unroll
-      for (int ks = 0; ks < C::KS; ++ks) {
-        uint4 wf[C::NW];
+    for (int i = 0; i < C::MW; ++i) xc[i] = *reinterpret_cast<const uint4*>(xaddr(i, 0));
 #pragma unroll
-        for (int j = 0; j < C::NW; ++j) wf[j] = wp[((size_t)j * C::KTOT + (ch * C::TAPS + t) * C::KS + ks) * 64];
+    for (int kk = 0; kk < NK; ++kk) {
+      if (kk + 1 < NK) {  // the next k-step's activation fragments are read while this step's MFMAs run
 #pragma unroll
-        for (int i = 0; i < C::MW; ++i) {
-          const uint4 xf = *reinterpret_cast<const uint4*>(smem + base[i] + toff + ks * 32);
-#pragma unroll
-          for (int j = 0; j < C::NW; ++j) mma_step<T>(acc[i][j], wf[j], xf);
-        }
+        for (int i = 0; i < C::MW; ++i) xn[i] = *reinterpret_cast<const uint4*>(xaddr(i, kk + 1));
       }
+      uint4 wf[C::NW];
+#pragma unroll
+      for (int j = 0; j < C::NW; ++j) wf[j] = wq[kk % PD][j];
+      if (kk + PD < NK) {
+#pragma unroll
+        for (int j = 0; j < C::NW; ++j) wq[kk % PD][j] = wp[((size_t)j * C::KTOT + ch * NK + kk + PD) * 64];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < C::MW; ++i)
+#pragma unroll
+        for (int j = 0; j < C::NW; ++j) mma_step<T>(acc[i][j], wf[j], xc[i]);
+#pragma unroll
+      for (int i = 0; i < C::MW; ++i) xc[i] = xn[i];
     }
   }
 

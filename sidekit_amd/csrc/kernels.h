@@ -19,6 +19,7 @@ struct ConvArgs {
   const float* shift;  // [COUT] folded BatchNorm shift
   void* out;           // [B][Hout][WOUT][COUT]
   float* se_part;      // [B][tiles][WM][COUT] per-workgroup plane sums, or nullptr
+  const void* zeros;   // >= 16 zero bytes in device memory (source of the conv zero padding)
   Lens lens;           // feature frames per utterance
   int halvings_in;     // stride-2 stages between the features and this conv's input
   int B, Hin, Hout;    // allocated rows of in / out

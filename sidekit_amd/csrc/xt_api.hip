@@ -83,6 +83,7 @@ struct xt_handle {
   float* d_dctT = nullptr;   // [n_out][n_mels] (MFCC)
 
   // halfresnet34
+  void* d_zeros = nullptr;
   float* stem_w = nullptr; float* stem_scale = nullptr; float* stem_shift = nullptr;
   std::vector<Block> blocks;
   float *att_w1x = nullptr, *att_w1c = nullptr, *att_b1 = nullptr, *att_bn_scale = nullptr, *att_bn_shift = nullptr;
@@ -284,6 +285,8 @@ static std::vector<float> normalize_rows(const std::vector<float>& w, int rows, 
 
 static int finalize_half(xt_handle* h) {
   const std::string sn = "sequence_network";
+  std::vector<float> zero64(64, 0.f);
+  SK_TRY(upload(h, zero64.data(), zero64.size() * 4, &h->d_zeros));
   SK_TRY(upload_f(h, T(h, sn + ".conv1.weight"), &h->stem_w));
   std::vector<float> sc, sh;
   fold_bn(h, sn + ".bn1", sc, sh);
@@ -525,7 +528,7 @@ static int half_from_feats(xt_handle* h, const float* feats, long sb, long sf, l
     const bool first = b.has_sc;
     const int lin = first ? (li == 0 ? 0 : li - 1) : li;  // layer index of the block input
     ConvArgs a;
-    a.lens = m.lens; a.B = B;
+    a.lens = m.lens; a.B = B; a.zeros = h->d_zeros;
     // conv1 (+bn1 +relu)
     a.in = X; a.wpack = b.c1.wpack; a.scale = b.c1.scale; a.shift = b.c1.shift; a.out = O1; a.se_part = nullptr;
     a.halvings_in = lin; a.Hin = Hl[lin]; a.Hout = Hl[li]; a.relu = 1;
