@@ -1,0 +1,18 @@
+"""Per-shape conv kernel timing with ablation variants (GPU box)."""
+import ctypes, sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from sidekit_amd import _lib
+lib = _lib.lib()
+torch.cuda.init(); torch.zeros(1).cuda()
+names = _lib.PROF_NAMES[:11]
+Ts = {0: 401, 1: 401, 2: 401, 3: 401, 4: 201, 5: 201, 6: 201, 7: 101, 8: 101, 9: 101, 10: 51}
+shapes = [int(x) for x in sys.argv[1].split(",")] if len(sys.argv) > 1 else [0, 4, 7, 10]
+variants = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0, 1, 2, 3, 4, 6]
+for sh in shapes:
+    row = []
+    for v in variants:
+        ms = ctypes.c_float(0)
+        _lib.check(lib.sk_bench_conv(sh, 1, 256, Ts[sh], 20, v, ctypes.byref(ms)))
+        row.append(f"v{v}={ms.value*1e3:.0f}us")
+    print(names[sh], " ".join(row), flush=True)

@@ -11,9 +11,9 @@
 //  * weights are pre-packed on the host in MFMA *fragment order* (64 lanes x 16 B per k-step), so
 //    every wave streams its A operand from L2 with perfectly coalesced 1-KiB loads and the LDS is
 //    left to the activations;
-//  * positions sit on the MFMA lanes, channels in the accumulator registers: each lane ends up
-//    with 4 consecutive output channels per register group -> 8-B (bf16) / 16-B (f32) NHWC stores
-//    with the BN scale/shift, ReLU and the squeeze-excite plane sums fused in the epilogue;
+//  * positions sit on the MFMA lanes, channels in the accumulator registers; the epilogue applies BN
+//    scale/shift, ReLU and the squeeze-excite plane sums in registers, transposes the tile through the
+//    consumed LDS buffer and writes it as contiguous 16-B-per-lane NHWC rows;
 //  * per-utterance lengths: rows >= the utterance's own row count are read as zero
 //    padding and never written, so a padded batch reproduces each utterance run alone.
 #include "kernels.h"
@@ -51,7 +51,6 @@ struct ConvCfg {
   static constexpr int NCH = CIN / CK;           // channel chunks
   static constexpr int KTOT = NCH * TAPS * KS;   // k-steps per output-channel tile
   static_assert(MT == WM * MW * 32, "positions must tile into 32-row MFMA tiles");
-  static_assert(WM * WN == 4, "four waves per workgroup");
   static_assert(COUT % NT == 0 && CIN % CK == 0 && CB % 32 == 0, "channel tiling");
   static_assert(LDS <= 160 * 1024, "LDS budget");
 };
@@ -59,10 +58,12 @@ struct ConvCfg {
 template <class C>
 __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
   using T = typename C::T;
+  static_assert(C::WM * C::WN == 4, "four waves per workgroup");
+  static_assert(C::NT == C::COUT, "one workgroup owns every output channel of its rows (contiguous NHWC out tile)");
   __shared__ __attribute__((aligned(1024))) unsigned char smem[C::LDS];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
-  const int wm = wave / C::WN, wn = wave % C::WN;
+  const int wm = __builtin_amdgcn_readfirstlane(wave / C::WN), wn = __builtin_amdgcn_readfirstlane(wave % C::WN);
   const int tiles = (a.Hout + C::TH - 1) / C::TH;
   // XCD-aware order: blocks are dealt round-robin over the 8 XCDs (bid % 8 shares an L2), so give every XCD a
   // contiguous run of (utterance, row-tile) work items -> vertically adjacent tiles share their halo rows in L2
@@ -73,7 +74,6 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
   const int hin_b = halve(a.lens.get(b), a.halvings_in);
   const int hout_b = (C::S == 2) ? ((hin_b + 1) >> 1) : hin_b;
   if (ho0 >= hout_b) return;  // nothing valid in this tile (its SE partial is never read)
-  const int n0 = blockIdx.y * C::NT + wn * C::NW * 32;
 
   int base[C::MW];
 #pragma unroll
@@ -90,7 +90,15 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
 
-  const uint4* wp = reinterpret_cast<const uint4*>(a.wpack) + (size_t)(n0 / 32) * C::KTOT * 64 + lane;
+  // Output-channel tile of (wave column wn, repeat j) = j*WN + wn: for a fixed j the workgroup's WN*32 channels are
+  // contiguous, so the staged out tile leaves as contiguous NHWC rows.  Fragment address = wave-uniform (SGPR)
+  // offset + 32-bit lane offset, so no per-fragment 64-bit VGPR address is kept alive.
+  const unsigned char* wbase = reinterpret_cast<const unsigned char*>(a.wpack);
+  const unsigned lane16 = (unsigned)lane * 16u;
+  auto wload = [&](int j, int kidx) {
+    const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane(((j * C::WN + wn) * C::KTOT + kidx) * 1024);
+    return *reinterpret_cast<const uint4*>(wbase + soff + lane16);
+  };
   const unsigned char* in = reinterpret_cast<const unsigned char*>(a.in);
   const int hi0 = ho0 * C::S - 1;
 
@@ -103,14 +111,15 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
 #pragma unroll
     for (int d = 0; d < PD; ++d)
 #pragma unroll
-      for (int j = 0; j < C::NW; ++j) wq[d][j] = wp[((size_t)j * C::KTOT + ch * NK + d) * 64];
+      for (int j = 0; j < C::NW; ++j) wq[d][j] = wload(j, ch * NK + d);
     __builtin_amdgcn_sched_barrier(0);  // keep the loads up here: the scheduler otherwise sinks them next to their use
     if (ch) __syncthreads();
     // stage the halo tile with LDS-DMA (global_load_lds_dwordx4: 64 lanes x 16 B land on 1 KiB of LDS, no VGPRs,
-    // every piece in flight at once).  A lane whose slot is a pad slot or a zero-padding position reads `zeros`.
+    // every piece in flight at once).  A lane whose slot is a pad slot or a zero-padding position reads the zero page
+    // (measured: masking those lanes off and zero-filling with ds_write instead is 20 % slower).
     constexpr int CPP = C::CB / 16, SPP = C::PSTRIDE / 16, NPIECE = C::LDS / 1024;
 #pragma unroll 2
-    for (int it = wave; it < NPIECE; it += 4) {
+    for (int it = (a.dbg & 4) ? NPIECE : wave; it < NPIECE; it += 4) {
       const int slot = it * 64 + lane;
       const int pos = slot / SPP, cc = slot % SPP;
       const int row = pos / C::WP, col = pos % C::WP;
@@ -130,6 +139,7 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
     uint4 xc[C::MW], xn[C::MW];
 #pragma unroll
     for (int i = 0; i < C::MW; ++i) xc[i] = *reinterpret_cast<const uint4*>(xaddr(i, 0));
+    if (!(a.dbg & 2))
 #pragma unroll
     for (int kk = 0; kk < NK; ++kk) {
       if (kk + 1 < NK) {  // the next k-step's activation fragments are read while this step's MFMAs run
@@ -141,7 +151,7 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
       for (int j = 0; j < C::NW; ++j) wf[j] = wq[kk % PD][j];
       if (kk + PD < NK) {
 #pragma unroll
-        for (int j = 0; j < C::NW; ++j) wq[kk % PD][j] = wp[((size_t)j * C::KTOT + ch * NK + kk + PD) * 64];
+        for (int j = 0; j < C::NW; ++j) wq[kk % PD][j] = wload(j, ch * NK + kk + PD);
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -153,26 +163,31 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
     }
   }
 
-  // ---- epilogue: BN scale/shift (+ReLU) -> NHWC store; SE plane sums ------------------------
+  // ---- epilogue: BN scale/shift (+ReLU), SE plane sums; the tile is transposed through the (now consumed) LDS
+  // halo buffer and leaves as whole 1-KiB, 16-B-per-lane NHWC stores (direct 8-B stores ran at 2.9 TB/s)
   unsigned char* out = reinterpret_cast<unsigned char*>(a.out);
+  constexpr int OPS = C::WN * 32 * C::EB + 16;  // out-tile position stride in LDS (padded against bank conflicts)
+  static_assert(C::MT * OPS <= C::LDS, "out tile must fit the consumed input buffer");
+  const int mvalid = (hout_b - ho0) * C::WOUT < C::MT ? (hout_b - ho0) * C::WOUT : C::MT;
+  const size_t gpos0 = ((size_t)b * a.Hout + ho0) * C::WOUT;
 #pragma unroll
   for (int j = 0; j < C::NW; ++j) {
+    __syncthreads();  // every wave is done with the halo tile (j == 0) / the previous sub-tile has been copied out
+    const int nbase = (j * C::WN + wn) * 32;
     float ssum[16];
 #pragma unroll
     for (int q = 0; q < 16; ++q) ssum[q] = 0.f;
     f32x4 sc[4], sh[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const int cb = n0 + j * 32 + 8 * g + 4 * h;
-      sc[g] = *reinterpret_cast<const f32x4*>(a.scale + cb);
-      sh[g] = *reinterpret_cast<const f32x4*>(a.shift + cb);
+      sc[g] = *reinterpret_cast<const f32x4*>(a.scale + nbase + 8 * g + 4 * h);
+      sh[g] = *reinterpret_cast<const f32x4*>(a.shift + nbase + 8 * g + 4 * h);
     }
 #pragma unroll
     for (int i = 0; i < C::MW; ++i) {
       const int m = (wm * C::MW + i) * 32 + r;
-      const int ho = ho0 + m / C::WOUT, wo = m % C::WOUT;
-      const bool valid = ho < hout_b;
-      unsigned char* op = out + ((((size_t)b * a.Hout + ho) * C::WOUT + wo) * C::COUT + n0 + j * 32 + 4 * h) * C::EB;
+      const bool valid = m < mvalid;
+      unsigned char* lp = smem + m * OPS + (wn * 32 + 4 * h) * C::EB;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         float v[4];
@@ -183,13 +198,8 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
           v[q] = x;
           ssum[4 * g + q] += valid ? x : 0.f;
         }
-        if (valid) {
-          if constexpr (C::EB == 2) {
-            *reinterpret_cast<uint2*>(op + 8 * g * 2) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
-          } else {
-            *reinterpret_cast<float4*>(op + 8 * g * 4) = make_float4(v[0], v[1], v[2], v[3]);
-          }
-        }
+        if constexpr (C::EB == 2) *reinterpret_cast<uint2*>(lp + 8 * g * 2) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+        else *reinterpret_cast<float4*>(lp + 8 * g * 4) = make_float4(v[0], v[1], v[2], v[3]);
       }
     }
     if (a.se_part) {
@@ -201,10 +211,19 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
         ssum[q] = s;
       }
       if (r == 0) {
-        float* sp = a.se_part + (((size_t)b * tiles + tile) * C::WM + wm) * C::COUT + n0 + j * 32 + 4 * h;
+        float* sp = a.se_part + (((size_t)b * tiles + tile) * C::WM + wm) * C::COUT + nbase + 4 * h;
 #pragma unroll
         for (int g = 0; g < 4; ++g)
           *reinterpret_cast<float4*>(sp + 8 * g) = make_float4(ssum[4 * g], ssum[4 * g + 1], ssum[4 * g + 2], ssum[4 * g + 3]);
+      }
+    }
+    __syncthreads();  // out sub-tile complete
+    if (!(a.dbg & 1)) {
+      constexpr int CPR = C::WN * 32 * C::EB / 16;  // 16-B chunks per position
+      for (int idx = tid; idx < mvalid * CPR; idx += 256) {
+        const int m = idx / CPR, cc = idx % CPR;
+        const uint4 v = *reinterpret_cast<const uint4*>(smem + m * OPS + cc * 16);
+        *reinterpret_cast<uint4*>(out + ((gpos0 + m) * C::COUT + j * C::WN * 32) * C::EB + cc * 16) = v;
       }
     }
   }
@@ -213,7 +232,7 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
 template <class C>
 static int launch_cfg(const ConvArgs& a, hipStream_t st) {
   const int tiles = cdiv(a.Hout, C::TH);
-  dim3 grid((unsigned)(a.B * tiles), C::COUT / C::NT);
+  dim3 grid((unsigned)(a.B * tiles));
   hipLaunchKernelGGL(conv3x3_kernel<C>, grid, dim3(256), 0, st, a);
   SK_HIP(hipGetLastError());
   return SK_OK;
@@ -243,7 +262,7 @@ using F_L3S  = ConvCfg<float,  64, 128, 2, 40,  8, 1, 4, 5, 1, 32, 1>;
 using F_L3   = ConvCfg<float, 128, 128, 1, 20,  8, 1, 4, 5, 1, 128, 9>;
 using F_L4A  = ConvCfg<float, 128, 256, 2, 20, 16, 1, 4, 5, 2, 32, 9>;
 using F_L4S  = ConvCfg<float, 128, 256, 2, 20, 16, 1, 4, 5, 2, 32, 1>;
-using F_L4   = ConvCfg<float, 256, 256, 1, 10, 16, 1, 4, 5, 2, 64, 9>;
+using F_L4   = ConvCfg<float, 256, 256, 1, 10, 16, 1, 4, 5, 2, 128, 9>;
 
 template <class C>
 static void fill_geom(ConvGeom& g) {

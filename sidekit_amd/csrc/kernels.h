@@ -24,6 +24,7 @@ struct ConvArgs {
   int halvings_in;     // stride-2 stages between the features and this conv's input
   int B, Hin, Hout;    // allocated rows of in / out
   int relu;
+  int dbg;             // diagnostics only (sk_bench_conv): bit0 skip stores, bit1 skip MFMA loop, bit2 skip staging
 };
 
 struct ConvGeom { int cin, cout, stride, win, th, wm, ck, taps, ks, eb; };

@@ -285,7 +285,7 @@ static std::vector<float> normalize_rows(const std::vector<float>& w, int rows, 
 
 static int finalize_half(xt_handle* h) {
   const std::string sn = "sequence_network";
-  std::vector<float> zero64(64, 0.f);
+  std::vector<float> zero64(64, 0.f);  // the zero page the conv staging reads its zero padding from
   SK_TRY(upload(h, zero64.data(), zero64.size() * 4, &h->d_zeros));
   SK_TRY(upload_f(h, T(h, sn + ".conv1.weight"), &h->stem_w));
   std::vector<float> sc, sh;
@@ -528,7 +528,7 @@ static int half_from_feats(xt_handle* h, const float* feats, long sb, long sf, l
     const bool first = b.has_sc;
     const int lin = first ? (li == 0 ? 0 : li - 1) : li;  // layer index of the block input
     ConvArgs a;
-    a.lens = m.lens; a.B = B; a.zeros = h->d_zeros;
+    a.lens = m.lens; a.B = B; a.zeros = h->d_zeros; a.dbg = 0;
     // conv1 (+bn1 +relu)
     a.in = X; a.wpack = b.c1.wpack; a.scale = b.c1.scale; a.shift = b.c1.shift; a.out = O1; a.se_part = nullptr;
     a.halvings_in = lin; a.Hin = Hl[lin]; a.Hout = Hl[li]; a.relu = 1;
@@ -882,6 +882,38 @@ int xt_get_profile(xt_handle* h, double* ms, int64_t* launches, int32_t reset) {
   h->prof_recs.clear();
   for (int i = 0; i < XT_PROF_SLOTS; ++i) { ms[i] = h->prof_ms[i]; launches[i] = h->prof_n[i]; }
   if (reset) for (int i = 0; i < XT_PROF_SLOTS; ++i) { h->prof_ms[i] = 0; h->prof_n[i] = 0; }
+  return SK_OK;
+}
+
+// Kernel-level timing harness for tuning (diagnostic; not used by the product path): runs one trunk
+// convolution shape `iters` times on zero-initialised buffers and returns the mean device time.
+int sk_bench_conv(int32_t shape, int32_t dtype, int32_t B, int32_t T, int32_t iters, int32_t variant, float* ms_out) {
+  SK_CHECK(ms_out && B > 0 && T > 0 && iters > 0, SK_EARG, "sk_bench_conv: bad arguments");
+  ConvGeom g;
+  const int dt = dtype == XT_BF16 ? DT_BF16 : DT_F32;
+  SK_TRY(conv_geom(shape, dt, &g));
+  const int hin = T, hout = g.stride == 2 ? (T + 1) / 2 : T;
+  const size_t in_b = (size_t)B * hin * g.win * g.cin * g.eb, out_b = (size_t)B * hout * (g.win / g.stride) * g.cout * g.eb;
+  void *in = nullptr, *out = nullptr, *w = nullptr, *zeros = nullptr; float *sc = nullptr, *sh = nullptr, *se = nullptr;
+  SK_HIP(hipMalloc(&in, in_b)); SK_HIP(hipMalloc(&out, out_b)); SK_HIP(hipMalloc(&w, conv_pack_bytes(g) + 4096));
+  SK_HIP(hipMalloc(&zeros, 256)); SK_HIP(hipMalloc((void**)&sc, g.cout * 4)); SK_HIP(hipMalloc((void**)&sh, g.cout * 4));
+  SK_HIP(hipMalloc((void**)&se, (size_t)B * (hout / g.th + 2) * 4 * g.cout * 4));
+  SK_HIP(hipMemset(in, 0x3c, in_b)); SK_HIP(hipMemset(w, 0x3c, conv_pack_bytes(g))); SK_HIP(hipMemset(zeros, 0, 256));
+  SK_HIP(hipMemset(sc, 0, g.cout * 4)); SK_HIP(hipMemset(sh, 0, g.cout * 4));
+  ConvArgs a;
+  a.in = in; a.wpack = w; a.scale = sc; a.shift = sh; a.out = out; a.se_part = (variant & 8) ? se : nullptr; a.zeros = zeros;
+  a.lens = Lens{nullptr, T}; a.halvings_in = 0; a.B = B; a.Hin = hin; a.Hout = hout; a.relu = 1; a.dbg = variant & 7;
+  hipEvent_t e0, e1;
+  SK_HIP(hipEventCreate(&e0)); SK_HIP(hipEventCreate(&e1));
+  for (int i = 0; i < 3; ++i) SK_TRY(launch_conv(shape, dt, a, nullptr));
+  SK_HIP(hipEventRecord(e0, nullptr));
+  for (int i = 0; i < iters; ++i) SK_TRY(launch_conv(shape, dt, a, nullptr));
+  SK_HIP(hipEventRecord(e1, nullptr));
+  SK_HIP(hipEventSynchronize(e1));
+  SK_HIP(hipEventElapsedTime(ms_out, e0, e1));
+  *ms_out /= iters;
+  (void)hipFree(in); (void)hipFree(out); (void)hipFree(w); (void)hipFree(zeros); (void)hipFree(sc); (void)hipFree(sh); (void)hipFree(se);
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   return SK_OK;
 }
 
