@@ -86,6 +86,21 @@ struct GemmArgs {
 GemmArgs gemm_args();   // zero-initialised, alpha = 1
 int launch_gemm(const GemmArgs& g, hipStream_t s);
 
+// ---- frontend_fft.hip ------------------------------------------------------------------------
+// |rFFT_1024(window * preemph(frame))|^2 for the log-mel front-end (n_fft 1024, win 400), one wave per frame
+struct FftArgs {
+  const float* wav; long wav_ld;
+  const int* nsamples; int nsamples_uniform;   // per-utterance sample counts (device) or one value for all
+  const float* window;                         // [400]
+  const float* tw512;                          // exp(-2 pi i m / 512),  m = 0..511, interleaved (re, im)
+  const float* tw1024;                         // exp(-2 pi i k / 1024), k = 0..512
+  float* P; long ldp;                          // [M][ldp] power spectrum, ldp >= 513 (extra columns zeroed)
+  int M, t_max, hop;
+  const int* row_b; const int* row_t;          // optional ragged row map
+  float preemph;
+};
+int launch_stft_power_fft(const FftArgs& a, hipStream_t s);
+
 // ---- pool.hip ---------------------------------------------------------------------------
 // rows layout: x[(row0[b] + t) * ld + d], t < count[b]
 struct RowSpan {

@@ -81,6 +81,8 @@ struct xt_handle {
   float* d_basis = nullptr;  // [2*nbp][win]
   float* d_fbT = nullptr;    // [n_mels][nbp]
   float* d_dctT = nullptr;   // [n_out][n_mels] (MFCC)
+  float* d_tw512 = nullptr;  // FFT twiddles (log-mel front-end)
+  float* d_tw1024 = nullptr;
 
   // halfresnet34
   void* d_zeros = nullptr;
@@ -262,6 +264,13 @@ static int build_frontend(xt_handle* h) {
   for (int j = 0; j < nb; ++j)
     for (int m = 0; m < f.n_mels; ++m) fbT[(size_t)m * h->nbp + j] = fb[(size_t)j * f.n_mels + m];
   SK_TRY(upload_f(h, fbT, &h->d_fbT));
+  if (mel) {  // twiddles of the 1024-point real FFT (frontend_fft.hip), rounded once from double
+    std::vector<float> t512(2 * 512), t1024(2 * 513);
+    for (int m = 0; m < 512; ++m) { t512[2 * m] = (float)cos(2.0 * M_PI * m / 512.0); t512[2 * m + 1] = (float)(-sin(2.0 * M_PI * m / 512.0)); }
+    for (int k = 0; k <= 512; ++k) { t1024[2 * k] = (float)cos(2.0 * M_PI * k / 1024.0); t1024[2 * k + 1] = (float)(-sin(2.0 * M_PI * k / 1024.0)); }
+    SK_TRY(upload_f(h, t512, &h->d_tw512));
+    SK_TRY(upload_f(h, t1024, &h->d_tw1024));
+  }
   if (!mel) {
     const auto& dct = T(h, "preprocessor.MFCC.dct_mat");  // [n_mels][n_out]
     std::vector<float> dT((size_t)f.n_out * f.n_mels);
@@ -462,17 +471,29 @@ static int ring_end(xt_handle* h, hipStream_t st) {
 static int frontend_rows(xt_handle* h, const float* d_wav, int64_t wav_ld, const BatchMeta& m, float* d_feat_rows, hipStream_t st) {
   const FrontCfg& f = h->fc;
   const int M = m.R ? m.R : m.B * m.T;
-  // 1) frames x DFT basis -> [re | im]
-  GemmArgs g = gemm_args();
-  g.a_mode = A_FRAMES; g.A = d_wav; g.wav_ld = wav_ld; g.window = h->d_window; g.nsamples = m.d_nsamples;
-  g.nsamples_uniform = m.nsamples_uniform; g.hop = f.hop; g.t_max = m.T; g.row_b = m.d_row_b; g.row_t = m.d_row_t;
-  g.preemph = 0.97f;
-  g.W = h->d_basis; g.ldw = f.win; g.C = (float*)h->ws_S.p; g.ldc = 2 * h->nbp; g.M = M; g.N = 2 * h->nbp; g.K = f.win;
-  SK_CHECK((size_t)M * 2 * h->nbp * 4 <= h->ws_S.bytes, SK_EWORKSPACE, "spectrum workspace too small (xt_reserve)");
-  { ProfScope ps(h, XT_PROF_FRONTEND, st); SK_TRY(launch_gemm(g, st)); }
-  // 2) |.|^2 x mel filterbank, log(. + 1e-6)
   GemmArgs p = gemm_args();
-  p.a_mode = A_POWER; p.A = h->ws_S.p; p.lda = 2 * h->nbp; p.kc = h->nbp;
+  if (h->cfg.arch == XT_ARCH_HALFRESNET34) {
+    // 1) |rFFT(window * preemph(frame))|^2, one wavefront per frame (frontend_fft.hip)
+    FftArgs fa;
+    fa.wav = d_wav; fa.wav_ld = wav_ld; fa.nsamples = m.d_nsamples; fa.nsamples_uniform = m.nsamples_uniform; fa.window = h->d_window;
+    fa.tw512 = h->d_tw512; fa.tw1024 = h->d_tw1024; fa.P = (float*)h->ws_S.p; fa.ldp = h->nbp; fa.M = M; fa.t_max = m.T; fa.hop = f.hop;
+    fa.row_b = m.d_row_b; fa.row_t = m.d_row_t; fa.preemph = 0.97f;
+    SK_CHECK((size_t)M * h->nbp * 4 <= h->ws_S.bytes, SK_EWORKSPACE, "spectrum workspace too small (xt_reserve)");
+    { ProfScope ps(h, XT_PROF_FRONTEND, st); SK_TRY(launch_stft_power_fft(fa, st)); }
+    // 2) power x mel filterbank, log(. + 1e-6)
+    p.a_mode = A_PLAIN; p.A = h->ws_S.p; p.lda = h->nbp; p.a_rows = M;
+  } else {
+    // 1) frames x DFT basis -> [re | im]   (MFCC front-end: n_fft 2048, win 1024)
+    GemmArgs g = gemm_args();
+    g.a_mode = A_FRAMES; g.A = d_wav; g.wav_ld = wav_ld; g.window = h->d_window; g.nsamples = m.d_nsamples;
+    g.nsamples_uniform = m.nsamples_uniform; g.hop = f.hop; g.t_max = m.T; g.row_b = m.d_row_b; g.row_t = m.d_row_t;
+    g.preemph = 0.97f;
+    g.W = h->d_basis; g.ldw = f.win; g.C = (float*)h->ws_S.p; g.ldc = 2 * h->nbp; g.M = M; g.N = 2 * h->nbp; g.K = f.win;
+    SK_CHECK((size_t)M * 2 * h->nbp * 4 <= h->ws_S.bytes, SK_EWORKSPACE, "spectrum workspace too small (xt_reserve)");
+    { ProfScope ps(h, XT_PROF_FRONTEND, st); SK_TRY(launch_gemm(g, st)); }
+    // 2) |.|^2 x mel filterbank, log(. + 1e-6)
+    p.a_mode = A_POWER; p.A = h->ws_S.p; p.lda = 2 * h->nbp; p.kc = h->nbp;
+  }
   p.W = h->d_fbT; p.ldw = h->nbp; p.M = M; p.N = f.n_mels; p.K = h->nbp; p.act = ACT_LOG_EPS;
   const bool mfcc = h->cfg.arch == XT_ARCH_TDNN;
   float* logmel = mfcc ? (float*)h->ws_act[3].p : d_feat_rows;
