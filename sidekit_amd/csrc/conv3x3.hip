@@ -55,10 +55,14 @@ struct ConvCfg {
   static_assert(LDS <= 160 * 1024, "LDS budget");
 };
 
+// second launch-bound = waves per SIMD: two workgroups per CU whenever two halo tiles fit the LDS, which caps the
+// kernel at 256 registers (VGPR + AGPR) per lane
 template <class C>
-__global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
+__global__ __launch_bounds__(C::WM * C::WN * 64, (C::MW * C::NW <= 5 && 160 * 1024 / C::LDS * C::WM * C::WN >= 8) ? 2 : 1)
+void conv3x3_kernel(ConvArgs a) {
   using T = typename C::T;
-  static_assert(C::WM * C::WN == 4, "four waves per workgroup");
+  constexpr int NWAVES = C::WM * C::WN, NTHREADS = NWAVES * 64;
+  static_assert(NWAVES == 2 || NWAVES == 4, "two or four waves per workgroup");
   static_assert(C::NT == C::COUT, "one workgroup owns every output channel of its rows (contiguous NHWC out tile)");
   __shared__ __attribute__((aligned(1024))) unsigned char smem[C::LDS];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -119,7 +123,7 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
     // (measured: masking those lanes off and zero-filling with ds_write instead is 20 % slower).
     constexpr int CPP = C::CB / 16, SPP = C::PSTRIDE / 16, NPIECE = C::LDS / 1024;
 #pragma unroll 2
-    for (int it = (a.dbg & 4) ? NPIECE : wave; it < NPIECE; it += 4) {
+    for (int it = (a.dbg & 4) ? NPIECE : wave; it < NPIECE; it += NWAVES) {
       const int slot = it * 64 + lane;
       const int pos = slot / SPP, cc = slot % SPP;
       const int row = pos / C::WP, col = pos % C::WP;
@@ -163,25 +167,48 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
     }
   }
 
-  // ---- epilogue: BN scale/shift (+ReLU), SE plane sums; the tile is transposed through the (now consumed) LDS
-  // halo buffer and leaves as whole 1-KiB, 16-B-per-lane NHWC stores (direct 8-B stores ran at 2.9 TB/s)
+  // ---- epilogue: BN scale/shift, then one of three forms:
+  //   plain      (+ReLU)                       -> store
+  //   statistics (+ReLU, conv1 of a block)     -> store + the sums the SE gate of the block is derived from
+  //   residual   (conv2 of a block)            -> * gate[b][c] + shortcut -> ReLU -> store
+  // The tile is transposed through the (now consumed) LDS halo buffer and leaves as whole 1-KiB, 16-B-per-lane NHWC
+  // rows (direct 8-B stores ran at 2.9 TB/s); the shortcut rows are read the same way in the residual form.
   unsigned char* out = reinterpret_cast<unsigned char*>(a.out);
-  constexpr int OPS = C::WN * 32 * C::EB + 16;  // out-tile position stride in LDS (padded against bank conflicts)
+  constexpr int NC = C::WN * 32;                // channels of one out sub-tile
+  constexpr int OPS = NC * C::EB + 16;          // out-tile position stride in LDS (padded against bank conflicts)
   static_assert(C::MT * OPS <= C::LDS, "out tile must fit the consumed input buffer");
   const int mvalid = (hout_b - ho0) * C::WOUT < C::MT ? (hout_b - ho0) * C::WOUT : C::MT;
   const size_t gpos0 = ((size_t)b * a.Hout + ho0) * C::WOUT;
+  auto lds_elem = [&](int m, int c) {
+    if constexpr (C::EB == 2) return bf16_to_f32(*reinterpret_cast<const uint16_t*>(smem + m * OPS + c * 2));
+    else return *reinterpret_cast<const float*>(smem + m * OPS + c * 4);
+  };
 #pragma unroll
   for (int j = 0; j < C::NW; ++j) {
     __syncthreads();  // every wave is done with the halo tile (j == 0) / the previous sub-tile has been copied out
     const int nbase = (j * C::WN + wn) * 32;
+    // residual form: this thread's shortcut chunks are fetched now and consumed after the out tile is staged
+    constexpr int CPR = NC * C::EB / 16;             // 16-B chunks per position
+    constexpr int NIT = (C::MT * CPR + NTHREADS - 1) / NTHREADS;   // copy-out iterations per thread
+    const unsigned char* scut = reinterpret_cast<const unsigned char*>(a.shortcut);
+    uint4 sreg[NIT];
+    if (a.gate) {
+#pragma unroll
+      for (int q = 0; q < NIT; ++q) {
+        const int idx = tid + q * NTHREADS, m = idx / CPR, cc = idx % CPR;
+        sreg[q] = (idx < mvalid * CPR) ? *reinterpret_cast<const uint4*>(scut + ((gpos0 + m) * C::COUT + j * NC) * C::EB + cc * 16)
+                                       : make_uint4(0, 0, 0, 0);
+      }
+    }
     float ssum[16];
 #pragma unroll
     for (int q = 0; q < 16; ++q) ssum[q] = 0.f;
-    f32x4 sc[4], sh[4];
+    f32x4 sc[4], sh[4], gt[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       sc[g] = *reinterpret_cast<const f32x4*>(a.scale + nbase + 8 * g + 4 * h);
       sh[g] = *reinterpret_cast<const f32x4*>(a.shift + nbase + 8 * g + 4 * h);
+      if (a.gate) gt[g] = *reinterpret_cast<const f32x4*>(a.gate + (size_t)b * C::COUT + nbase + 8 * g + 4 * h);
     }
 #pragma unroll
     for (int i = 0; i < C::MW; ++i) {
@@ -194,7 +221,9 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           float x = acc[i][j][4 * g + q] * sc[g][q] + sh[g][q];
-          if (a.relu) x = relu_nan(x);
+          if (a.gate) x *= gt[g][q];
+          else if (a.relu) x = relu_nan(x);
+          if constexpr (C::EB == 2) x = bf16_to_f32(f32_to_bf16(x));  // what is stored (and what the next conv reads)
           v[q] = x;
           ssum[4 * g + q] += valid ? x : 0.f;
         }
@@ -218,12 +247,56 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a) {
       }
     }
     __syncthreads();  // out sub-tile complete
+    if (a.se_part && tid < NC) {
+      // edge sums for the next conv's zero padding: a tap shifted by (dh, dw) misses one border row and/or column
+      const int c = tid, cg = j * NC + c, rows_valid = mvalid / C::WOUT, hl = hout_b - 1;
+      float c0 = 0.f, cl = 0.f;
+      for (int hr = 0; hr < rows_valid; ++hr) {
+        c0 += lds_elem(hr * C::WOUT, c);
+        cl += lds_elem(hr * C::WOUT + C::WOUT - 1, c);
+      }
+      float* cp = a.col_part + ((size_t)b * tiles + tile) * 2 * C::COUT + cg;
+      cp[0] = c0;
+      cp[C::COUT] = cl;
+      float* eg = a.edge + (size_t)b * 6 * C::COUT + cg;
+      if (tile == 0) {
+        float s = 0.f;
+        for (int wo = 0; wo < C::WOUT; ++wo) s += lds_elem(wo, c);
+        eg[0] = s;
+        eg[2 * C::COUT] = lds_elem(0, c);
+        eg[3 * C::COUT] = lds_elem(C::WOUT - 1, c);
+      }
+      if (tile == hl / C::TH) {
+        const int m0 = (hl - ho0) * C::WOUT;
+        float s = 0.f;
+        for (int wo = 0; wo < C::WOUT; ++wo) s += lds_elem(m0 + wo, c);
+        eg[1 * C::COUT] = s;
+        eg[4 * C::COUT] = lds_elem(m0, c);
+        eg[5 * C::COUT] = lds_elem(m0 + C::WOUT - 1, c);
+      }
+    }
     if (!(a.dbg & 1)) {
-      constexpr int CPR = C::WN * 32 * C::EB / 16;  // 16-B chunks per position
-      for (int idx = tid; idx < mvalid * CPR; idx += 256) {
-        const int m = idx / CPR, cc = idx % CPR;
-        const uint4 v = *reinterpret_cast<const uint4*>(smem + m * OPS + cc * 16);
-        *reinterpret_cast<uint4*>(out + ((gpos0 + m) * C::COUT + j * C::WN * 32) * C::EB + cc * 16) = v;
+#pragma unroll
+      for (int q = 0; q < NIT; ++q) {
+        const int idx = tid + q * NTHREADS, m = idx / CPR, cc = idx % CPR;
+        if (idx >= mvalid * CPR) break;
+        uint4 v = *reinterpret_cast<const uint4*>(smem + m * OPS + cc * 16);
+        if (a.gate) {
+          const uint4 s = sreg[q];
+          if constexpr (C::EB == 2) {
+            const uint32_t vv[4] = {v.x, v.y, v.z, v.w}, ss[4] = {s.x, s.y, s.z, s.w};
+            uint32_t rr[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              rr[e] = pack_bf16x2(relu_nan(bf16_to_f32(vv[e] & 0xffff) + bf16_to_f32(ss[e] & 0xffff)),
+                                  relu_nan(bf16_to_f32(vv[e] >> 16) + bf16_to_f32(ss[e] >> 16)));
+            v = make_uint4(rr[0], rr[1], rr[2], rr[3]);
+          } else {
+            const float4 vf = __builtin_bit_cast(float4, v), sf = __builtin_bit_cast(float4, s);
+            v = __builtin_bit_cast(uint4, make_float4(relu_nan(vf.x + sf.x), relu_nan(vf.y + sf.y), relu_nan(vf.z + sf.z), relu_nan(vf.w + sf.w)));
+          }
+        }
+        *reinterpret_cast<uint4*>(out + ((gpos0 + m) * C::COUT + j * NC) * C::EB + cc * 16) = v;
       }
     }
   }
@@ -233,7 +306,7 @@ template <class C>
 static int launch_cfg(const ConvArgs& a, hipStream_t st) {
   const int tiles = cdiv(a.Hout, C::TH);
   dim3 grid((unsigned)(a.B * tiles));
-  hipLaunchKernelGGL(conv3x3_kernel<C>, grid, dim3(256), 0, st, a);
+  hipLaunchKernelGGL(conv3x3_kernel<C>, grid, dim3(C::WM * C::WN * 64), 0, st, a);
   SK_HIP(hipGetLastError());
   return SK_OK;
 }

@@ -18,7 +18,14 @@ struct ConvArgs {
   const float* scale;  // [COUT] folded BatchNorm scale
   const float* shift;  // [COUT] folded BatchNorm shift
   void* out;           // [B][Hout][WOUT][COUT]
-  float* se_part;      // [B][tiles][WM][COUT] per-workgroup plane sums, or nullptr
+  // -- statistics mode (conv1 of a BasicBlock; se_part != nullptr): sums of the stored (rounded) output that determine
+  //    the plane mean of the 3x3 convolution that FOLLOWS (SELayer input, res_net.py:278-279) by linearity
+  float* se_part;      // [B][tiles][WM][COUT] per-workgroup totals
+  float* col_part;     // [B][tiles][2][COUT]  first / last column sums over the tile's valid rows
+  float* edge;         // [B][6][COUT]         first-row sum, last-row sum, corners (0,0) (0,W-1) (last,0) (last,W-1)
+  // -- residual mode (conv2 of a BasicBlock; gate != nullptr): out = relu(bn(conv) * gate[b][c] + shortcut)  (res_net.py:316-319)
+  const float* gate;   // [B][COUT]
+  const void* shortcut;  // NHWC, same shape and type as out
   const void* zeros;   // >= 16 zero bytes in device memory (source of the conv zero padding)
   Lens lens;           // feature frames per utterance
   int halvings_in;     // stride-2 stages between the features and this conv's input
@@ -38,12 +45,20 @@ void conv_pack_weights(const ConvGeom& g, const float* w, int kh_kw, void* dst);
 // stem: features (strides sf, st in elements) -> relu(bn(conv3x3 1->32)) NHWC [B][T][80][32]
 int launch_stem(const float* feats, long sb, long sf, long st, const float* w /*[32][9]*/, const float* scale,
                 const float* shift, void* out, int dtype, Lens lens, int B, int T, hipStream_t s);
-// SE gate: plane sums -> mean -> FC -> ReLU -> FC -> sigmoid
-int launch_se_gate(const float* se_part, int tiles, int wm, int th, const float* w1, const float* w2, float* gate,
-                   Lens lens, int halvings_out, int wout, int C, int B, hipStream_t s);
-// y = relu(o2 * gate[b][c] + sc)
-int launch_residual(const void* o2, const float* gate, const void* sc, void* y, int dtype, int B, long plane /*H*W*/,
-                    int C, hipStream_t s);
+// SE gate of a BasicBlock computed BEFORE its second convolution runs: the plane mean of bn2(conv2(o1)) is linear in
+// o1, so it follows from the sums conv1 left behind (total, first/last row and column, corners) and conv2's weights:
+//   mean[co] = scale2[co] / (H W) * sum_{ci,dh,dw} W2[co][ci][dh][dw] * S[ci][dh][dw] + shift2[co]
+// then FC -> ReLU -> FC -> sigmoid (res_net.py:262-281).
+struct SeArgs {
+  const float* se_part; const float* col_part; const float* edge;   // as written by the statistics-mode conv
+  int tiles, wm, th;
+  const float* w2t;      // conv2 weights as consumed by the MFMA (bf16-rounded in the bf16 path), [tap][ci][co] f32
+  const float* scale2; const float* shift2;
+  const float* fc1; const float* fc2;   // se.fc.0 [C/16][C], se.fc.2 [C][C/16]
+  float* gate;           // [B][C]
+  Lens lens; int halvings; int wout; int C; int B;
+};
+int launch_se_pre(const SeArgs& a, hipStream_t s);
 
 // ---- gemm.hip ---------------------------------------------------------------------------
 // C[m][n] = epi( sum_k A(m,k) * W[n][k] ), fp32 MFMA (exact f32 FMA chain), W row-major [N][K].

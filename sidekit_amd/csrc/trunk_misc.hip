@@ -1,6 +1,6 @@
-// Small trunk kernels around the 3x3 convolutions: stem conv (1->32), squeeze-excite gate,
-// gate*x + shortcut + ReLU.  Reference: sidekit/nnet/res_net.py:272-281 (SELayer),
-// :309-320 (BasicBlock tail), :509-515,549 (stem).  All HBM-bound: 16-B vector accesses.
+// Small trunk kernels around the 3x3 convolutions: stem conv (1->32) and the squeeze-excite gate.
+// Reference: sidekit/nnet/res_net.py:272-281 (SELayer), :509-515,549 (stem).  The block tail
+// (gate * out + shortcut, ReLU; res_net.py:316-319) lives in the second convolution's epilogue.
 #include "kernels.h"
 
 namespace sk {
@@ -75,90 +75,73 @@ int launch_stem(const float* feats, long sb, long sf, long st, const float* w, c
   return SK_OK;
 }
 
-// ---- SE gate -----------------------------------------------------------------------------------
-// One workgroup per utterance, one thread per channel.  Partial plane sums are added in a fixed
-// order (tile, wave) so the result is bitwise reproducible.
-__global__ void se_gate_kernel(const float* __restrict__ se_part, int tiles, int wm, int th,
-                               const float* __restrict__ w1, const float* __restrict__ w2, float* __restrict__ gate,
-                               Lens lens, int halvings_out, int wout, int C) {
+// ---- SE gate from conv1's output sums -----------------------------------------------------------------
+// One workgroup per utterance, one thread per channel.  Partial sums are added in a fixed order (tile, wave) so the
+// result is bitwise reproducible.  For the tap shifted by (dh, dw) the sum of the shifted, zero-padded plane is
+//   S = T - R(excluded border row) - C(excluded border column) + corner(both excluded).
+// 1024 threads = G groups of C channels: the groups split the tile range and the (tap, ci) range, partial results
+// are combined through LDS in group order.
+__global__ __launch_bounds__(1024) void se_pre_kernel(SeArgs a) {
+  __shared__ float red[3 * 1024];
+  __shared__ float S[9 * 256];
   __shared__ float y[256];
   __shared__ float hid[16];
-  const int b = blockIdx.x, c = threadIdx.x;
-  const int hb = halve(lens.get(b), halvings_out);
-  const int nt = (hb + th - 1) / th;
-  float s = 0.f;
-  for (int t = 0; t < nt; ++t)
-    for (int w = 0; w < wm; ++w) s += se_part[(((size_t)b * tiles + t) * wm + w) * C + c];
-  y[c] = s / (float)(hb * wout);
+  const int b = blockIdx.x, C = a.C, G = 1024 / C, c = threadIdx.x % C, g = threadIdx.x / C;
+  const int hb = halve(a.lens.get(b), a.halvings);
+  const int nt = (hb + a.th - 1) / a.th;
+  float T = 0.f, C0 = 0.f, CL = 0.f;
+  for (int t = g; t < nt; t += G) {
+    for (int w = 0; w < a.wm; ++w) T += a.se_part[(((size_t)b * a.tiles + t) * a.wm + w) * C + c];
+    C0 += a.col_part[((size_t)b * a.tiles + t) * 2 * C + c];
+    CL += a.col_part[((size_t)b * a.tiles + t) * 2 * C + C + c];
+  }
+  red[threadIdx.x] = T; red[1024 + threadIdx.x] = C0; red[2048 + threadIdx.x] = CL;
+  __syncthreads();
+  if (g == 0) {
+    T = 0.f; C0 = 0.f; CL = 0.f;
+    for (int q = 0; q < G; ++q) { T += red[q * C + c]; C0 += red[1024 + q * C + c]; CL += red[2048 + q * C + c]; }
+    const float* eg = a.edge + (size_t)b * 6 * C + c;
+    const float R0 = eg[0], RL = eg[C], k00 = eg[2 * C], k0L = eg[3 * C], kL0 = eg[4 * C], kLL = eg[5 * C];
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        // dh = kh - 1: a tap with dh < 0 never reaches the last row, dh > 0 never the first; same for columns
+        const float rex = kh == 0 ? RL : (kh == 2 ? R0 : 0.f);
+        const float cex = kw == 0 ? CL : (kw == 2 ? C0 : 0.f);
+        const float corner = (kh == 0 && kw == 0) ? kLL : (kh == 0 && kw == 2) ? kL0 : (kh == 2 && kw == 0) ? k0L : (kh == 2 && kw == 2) ? k00 : 0.f;
+        S[(kh * 3 + kw) * C + c] = T - rex - cex + corner;
+      }
+  }
+  __syncthreads();
+  float m = 0.f;
+#pragma unroll 8
+  for (int k = g; k < 9 * C; k += G) m = fmaf(a.w2t[(size_t)k * C + c], S[k], m);   // k = tap * C + ci
+  red[threadIdx.x] = m;
+  __syncthreads();
+  if (g == 0) {
+    m = 0.f;
+    for (int q = 0; q < G; ++q) m += red[q * C + c];
+    y[c] = m / (float)(hb * a.wout) * a.scale2[c] + a.shift2[c];
+  }
   __syncthreads();
   const int R = C / 16;
-  if (c < R) {
-    float a = 0.f;
-    for (int k = 0; k < C; ++k) a = fmaf(w1[c * C + k], y[k], a);
-    hid[c] = relu_nan(a);
+  if (threadIdx.x < R) {
+    float s = 0.f;
+    for (int k = 0; k < C; ++k) s = fmaf(a.fc1[threadIdx.x * C + k], y[k], s);
+    hid[threadIdx.x] = relu_nan(s);
   }
   __syncthreads();
-  float z = 0.f;
-  for (int k = 0; k < R; ++k) z = fmaf(w2[c * R + k], hid[k], z);
-  gate[(size_t)b * C + c] = 1.f / (1.f + expf(-z));
-}
-
-int launch_se_gate(const float* se_part, int tiles, int wm, int th, const float* w1, const float* w2, float* gate,
-                   Lens lens, int halvings_out, int wout, int C, int B, hipStream_t s) {
-  SK_CHECK(C <= 256 && C % 16 == 0, SK_EARG, "se_gate: C=%d unsupported", C);
-  hipLaunchKernelGGL(se_gate_kernel, dim3(B), dim3(C), 0, s, se_part, tiles, wm, th, w1, w2, gate, lens, halvings_out,
-                     wout, C);
-  SK_HIP(hipGetLastError());
-  return SK_OK;
-}
-
-// ---- y = relu(o2 * gate + shortcut) ----------------------------------------------------------------
-template <int EB>
-__global__ __launch_bounds__(256) void residual_kernel(const uint4* __restrict__ o2, const float* __restrict__ gate,
-                                                       const uint4* __restrict__ sc, uint4* __restrict__ y, long nvec,
-                                                       long vec_per_utt, int C) {
-  constexpr int VE = 16 / EB;
-  for (long i = blockIdx.x * 256L + threadIdx.x; i < nvec; i += (long)gridDim.x * 256L) {
-    const int b = (int)(i / vec_per_utt);
-    const int c = (int)((i * VE) % C);
-    const float* g = gate + (size_t)b * C + c;
-    const uint4 a = o2[i], s = sc[i];
-    uint4 r;
-    if constexpr (EB == 2) {
-      const uint32_t av[4] = {a.x, a.y, a.z, a.w}, sv[4] = {s.x, s.y, s.z, s.w};
-      uint32_t rv[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float lo = relu_nan(bf16_to_f32(av[q] & 0xffff) * g[2 * q] + bf16_to_f32(sv[q] & 0xffff));
-        const float hi = relu_nan(bf16_to_f32(av[q] >> 16) * g[2 * q + 1] + bf16_to_f32(sv[q] >> 16));
-        rv[q] = pack_bf16x2(lo, hi);
-      }
-      r = make_uint4(rv[0], rv[1], rv[2], rv[3]);
-    } else {
-      const float4 af = __builtin_bit_cast(float4, a), sf = __builtin_bit_cast(float4, s);
-      float4 rf;
-      rf.x = relu_nan(af.x * g[0] + sf.x);
-      rf.y = relu_nan(af.y * g[1] + sf.y);
-      rf.z = relu_nan(af.z * g[2] + sf.z);
-      rf.w = relu_nan(af.w * g[3] + sf.w);
-      r = __builtin_bit_cast(uint4, rf);
-    }
-    y[i] = r;
+  if (g == 0) {
+    float z = 0.f;
+    for (int k = 0; k < R; ++k) z = fmaf(a.fc2[c * R + k], hid[k], z);
+    a.gate[(size_t)b * C + c] = 1.f / (1.f + expf(-z));
   }
 }
 
-int launch_residual(const void* o2, const float* gate, const void* sc, void* y, int dtype, int B, long plane, int C,
-                    hipStream_t s) {
-  const int EB = dtype == DT_BF16 ? 2 : 4;
-  const long vec_per_utt = plane * C * EB / 16;
-  const long nvec = vec_per_utt * B;
-  const int grid = (int)((nvec + 255) / 256 < 8192 ? (nvec + 255) / 256 : 8192);
-  if (dtype == DT_BF16)
-    hipLaunchKernelGGL(residual_kernel<2>, dim3(grid), dim3(256), 0, s, (const uint4*)o2, gate, (const uint4*)sc,
-                       (uint4*)y, nvec, vec_per_utt, C);
-  else
-    hipLaunchKernelGGL(residual_kernel<4>, dim3(grid), dim3(256), 0, s, (const uint4*)o2, gate, (const uint4*)sc,
-                       (uint4*)y, nvec, vec_per_utt, C);
+int launch_se_pre(const SeArgs& a, hipStream_t s) {
+  SK_CHECK(a.C <= 256 && a.C % 16 == 0 && 1024 % a.C == 0, SK_EARG, "se_pre: C=%d unsupported", a.C);
+  hipLaunchKernelGGL(se_pre_kernel, dim3(a.B), dim3(1024), 0, s, a);
   SK_HIP(hipGetLastError());
   return SK_OK;
 }

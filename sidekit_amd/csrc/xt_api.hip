@@ -46,6 +46,7 @@ struct Block {
   bool has_sc = false;
   float* se_w1 = nullptr;
   float* se_w2 = nullptr;
+  float* w2t = nullptr;  // conv2 weights as the MFMA consumes them, [tap][ci][co] f32 (SE gate pre-computation)
   int C, li;
 };
 
@@ -98,7 +99,7 @@ struct xt_handle {
 
   // workspace
   int max_batch = 0; int64_t max_samples = 0;
-  DevBuf ws_S, ws_feat, ws_act[4], ws_se, ws_gate, ws_ctx, ws_rb, ws_h, ws_e, ws_pooled, ws_pre, ws_emb, ws_int, ws_ragged;
+  DevBuf ws_S, ws_feat, ws_act[4], ws_se, ws_col, ws_edge, ws_gate, ws_ctx, ws_rb, ws_h, ws_e, ws_pooled, ws_pre, ws_emb, ws_int, ws_ragged;
   // pinned staging ring for per-utterance integers
   static constexpr int RING = 4;
   int* ring_host[RING] = {nullptr, nullptr, nullptr, nullptr};
@@ -313,6 +314,19 @@ static int finalize_half(xt_handle* h) {
       SK_TRY(make_conv(h, b.c2, rest_shape[li], p + ".conv2.weight", p + ".bn2"));
       b.has_sc = bi == 0;
       if (b.has_sc) SK_TRY(make_conv(h, b.sc, sc_shape[li], p + ".shortcut.0.weight", p + ".shortcut.1"));
+      {
+        const auto& w2 = T(h, p + ".conv2.weight");  // [co][ci][3][3]
+        const int Cb = b.C;
+        std::vector<float> w2t((size_t)9 * Cb * Cb);
+        const bool bf = h->cfg.dtype == XT_BF16;
+        for (int co = 0; co < Cb; ++co)
+          for (int ci = 0; ci < Cb; ++ci)
+            for (int t = 0; t < 9; ++t) {
+              const float v = w2[((size_t)co * Cb + ci) * 9 + t];
+              w2t[((size_t)t * Cb + ci) * Cb + co] = bf ? bf16_to_f32(f32_to_bf16(v)) : v;
+            }
+        SK_TRY(upload_f(h, w2t, &b.w2t));
+      }
       SK_TRY(upload_f(h, T(h, p + ".se.fc.0.weight"), &b.se_w1));
       SK_TRY(upload_f(h, T(h, p + ".se.fc.2.weight"), &b.se_w2));
       h->blocks.push_back(b);
@@ -548,29 +562,36 @@ static int half_from_feats(xt_handle* h, const float* feats, long sb, long sf, l
     const int li = b.li;
     const bool first = b.has_sc;
     const int lin = first ? (li == 0 ? 0 : li - 1) : li;  // layer index of the block input
+    const int wout = 80 >> li;
     ConvArgs a;
-    a.lens = m.lens; a.B = B; a.zeros = h->d_zeros; a.dbg = 0;
-    // conv1 (+bn1 +relu)
-    a.in = X; a.wpack = b.c1.wpack; a.scale = b.c1.scale; a.shift = b.c1.shift; a.out = O1; a.se_part = nullptr;
+    memset(&a, 0, sizeof(a));
+    a.lens = m.lens; a.B = B; a.zeros = h->d_zeros;
+    // conv1 + bn1 + relu -> O1, leaving the sums the block's SE gate is derived from
+    a.in = X; a.wpack = b.c1.wpack; a.scale = b.c1.scale; a.shift = b.c1.shift; a.out = O1;
+    a.se_part = (float*)h->ws_se.p; a.col_part = (float*)h->ws_col.p; a.edge = (float*)h->ws_edge.p;
     a.halvings_in = lin; a.Hin = Hl[lin]; a.Hout = Hl[li]; a.relu = 1;
     { ProfScope ps(h, b.c1.shape, st); SK_TRY(launch_conv(b.c1.shape, dt, a, st)); }
-    // conv2 (+bn2) with SE plane sums
-    a.in = O1; a.wpack = b.c2.wpack; a.scale = b.c2.scale; a.shift = b.c2.shift; a.out = O2; a.se_part = (float*)h->ws_se.p;
-    a.halvings_in = li; a.Hin = Hl[li]; a.Hout = Hl[li]; a.relu = 0;
-    { ProfScope ps(h, b.c2.shape, st); SK_TRY(launch_conv(b.c2.shape, dt, a, st)); }
     const void* shortcut = X;
     if (first) {  // 1x1 conv (stride s) + bn on the block input
-      a.in = X; a.wpack = b.sc.wpack; a.scale = b.sc.scale; a.shift = b.sc.shift; a.out = SC; a.se_part = nullptr;
-      a.halvings_in = lin; a.Hin = Hl[lin]; a.Hout = Hl[li]; a.relu = 0;
+      a.wpack = b.sc.wpack; a.scale = b.sc.scale; a.shift = b.sc.shift; a.out = SC;
+      a.se_part = nullptr; a.col_part = nullptr; a.edge = nullptr; a.relu = 0;
       { ProfScope ps(h, b.sc.shape, st); SK_TRY(launch_conv(b.sc.shape, dt, a, st)); }
       shortcut = SC;
     }
-    const int wout = 80 >> li;
-    { ProfScope ps(h, XT_PROF_SE_RES, st);
-      SK_TRY(launch_se_gate((const float*)h->ws_se.p, cdiv(Hl[li], b.c2.g.th), b.c2.g.wm, b.c2.g.th, b.se_w1, b.se_w2,
-                            (float*)h->ws_gate.p, m.lens, li, wout, b.C, B, st));
-      SK_TRY(launch_residual(O2, (const float*)h->ws_gate.p, shortcut, O1, dt, B, (long)Hl[li] * wout, b.C, st)); }
-    std::swap(X, O1);
+    {  // SE gate, known before conv2 runs (linearity of the plane mean in O1)
+      SeArgs se;
+      se.se_part = (const float*)h->ws_se.p; se.col_part = (const float*)h->ws_col.p; se.edge = (const float*)h->ws_edge.p;
+      se.tiles = cdiv(Hl[li], b.c1.g.th); se.wm = b.c1.g.wm; se.th = b.c1.g.th; se.w2t = b.w2t; se.scale2 = b.c2.scale; se.shift2 = b.c2.shift;
+      se.fc1 = b.se_w1; se.fc2 = b.se_w2; se.gate = (float*)h->ws_gate.p; se.lens = m.lens; se.halvings = li; se.wout = wout; se.C = b.C; se.B = B;
+      ProfScope ps(h, XT_PROF_SE_RES, st);
+      SK_TRY(launch_se_pre(se, st));
+    }
+    // conv2 + bn2, * gate, + shortcut, relu -> O2 (the block output)
+    a.in = O1; a.wpack = b.c2.wpack; a.scale = b.c2.scale; a.shift = b.c2.shift; a.out = O2;
+    a.se_part = nullptr; a.col_part = nullptr; a.edge = nullptr; a.gate = (const float*)h->ws_gate.p; a.shortcut = shortcut;
+    a.halvings_in = li; a.Hin = Hl[li]; a.Hout = Hl[li]; a.relu = 0;
+    { ProfScope ps(h, b.c2.shape, st); SK_TRY(launch_conv(b.c2.shape, dt, a, st)); }
+    std::swap(X, O2);
     const bool last_of_layer = (bi + 1 == h->blocks.size()) || (h->blocks[bi + 1].li != li);
     if (last_of_layer) {
       const std::string nm = "layer" + std::to_string(li + 1);
@@ -720,7 +741,7 @@ int xt_create(const xt_config* cfg, xt_handle** out) {
 int xt_destroy(xt_handle* h) {
   if (!h) return SK_OK;
   for (void* p : h->dev_allocs) (void)hipFree(p);
-  DevBuf* bufs[] = {&h->ws_S, &h->ws_feat, &h->ws_act[0], &h->ws_act[1], &h->ws_act[2], &h->ws_act[3], &h->ws_se, &h->ws_gate,
+  DevBuf* bufs[] = {&h->ws_S, &h->ws_feat, &h->ws_act[0], &h->ws_act[1], &h->ws_act[2], &h->ws_act[3], &h->ws_se, &h->ws_col, &h->ws_edge, &h->ws_gate,
                     &h->ws_ctx, &h->ws_rb, &h->ws_h, &h->ws_e, &h->ws_pooled, &h->ws_pre, &h->ws_emb, &h->ws_int, &h->ws_ragged};
   for (DevBuf* b : bufs) b->release();
   for (auto& kv : h->taps) kv.second.buf.release();
@@ -799,6 +820,8 @@ int xt_reserve(xt_handle* h, int32_t max_batch, int64_t max_samples) {
     const size_t EB = h->cfg.dtype == XT_BF16 ? 2 : 4;
     for (int i = 0; i < 4; ++i) SK_TRY(h->ws_act[i].ensure(R * 80 * 32 * EB));
     SK_TRY(h->ws_se.ensure(B * ((T + 7) / 8 + 1) * 4 * 32 * 4 * 2));
+    SK_TRY(h->ws_col.ensure(B * ((T + 7) / 8 + 1) * 2 * 32 * 4 * 2));
+    SK_TRY(h->ws_edge.ensure(B * 6 * 256 * 4));
     SK_TRY(h->ws_gate.ensure(B * 256 * 4));
     const size_t H4 = (size_t)halve((int)T, 3);
     SK_TRY(h->ws_ctx.ensure(B * 5120 * 4));
@@ -922,7 +945,8 @@ int sk_bench_conv(int32_t shape, int32_t dtype, int32_t B, int32_t T, int32_t it
   SK_HIP(hipMemset(in, 0x3c, in_b)); SK_HIP(hipMemset(w, 0x3c, conv_pack_bytes(g))); SK_HIP(hipMemset(zeros, 0, 256));
   SK_HIP(hipMemset(sc, 0, g.cout * 4)); SK_HIP(hipMemset(sh, 0, g.cout * 4));
   ConvArgs a;
-  a.in = in; a.wpack = w; a.scale = sc; a.shift = sh; a.out = out; a.se_part = (variant & 8) ? se : nullptr; a.zeros = zeros;
+  memset(&a, 0, sizeof(a));
+  a.in = in; a.wpack = w; a.scale = sc; a.shift = sh; a.out = out; a.se_part = nullptr; a.zeros = zeros;
   a.lens = Lens{nullptr, T}; a.halvings_in = 0; a.B = B; a.Hin = hin; a.Hout = hout; a.relu = 1; a.dbg = variant & 7;
   hipEvent_t e0, e1;
   SK_HIP(hipEventCreate(&e0)); SK_HIP(hipEventCreate(&e1));
