@@ -109,8 +109,9 @@ int xt_set_profile(xt_handle* h, int32_t on);
 int xt_get_profile(xt_handle* h, double* ms /*[XT_PROF_SLOTS]*/, int64_t* launches /*[XT_PROF_SLOTS]*/, int32_t reset);
 
 /* Tuning harness (diagnostic): mean device ms of `iters` launches of trunk convolution `shape` (slot order of
- * xt_get_profile) on a B x T batch; variant bit0 = no stores, bit1 = no MFMA loop, bit2 = no staging, bit3 = SE sums. */
-int sk_bench_conv(int32_t shape, int32_t dtype, int32_t B, int32_t T, int32_t iters, int32_t variant, float* ms_out);
+ * xt_get_profile) on a B x T batch; variant bit0 = no stores, bit1 = no MFMA loop, bit2 = no staging, bit3 = statistics epilogue, bit4 = residual epilogue. */
+int sk_bench_conv(int32_t shape, int32_t dtype, int32_t B, int32_t T, int32_t iters, int32_t variant, float* ms_out,
+                  double* phase_cycles /* [8] mean shader cycles per kernel phase, or NULL */);
 
 const char* xt_last_error(void);
 

@@ -8,11 +8,16 @@ torch.cuda.init(); torch.zeros(1).cuda()
 names = _lib.PROF_NAMES[:11]
 Ts = {0: 401, 1: 401, 2: 401, 3: 401, 4: 201, 5: 201, 6: 201, 7: 101, 8: 101, 9: 101, 10: 51}
 shapes = [int(x) for x in sys.argv[1].split(",")] if len(sys.argv) > 1 else [0, 4, 7, 10]
+STAMPS = os.environ.get("STAMPS", "0") == "1"
 variants = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0, 1, 2, 3, 4, 6]
 for sh in shapes:
     row = []
     for v in variants:
         ms = ctypes.c_float(0)
-        _lib.check(lib.sk_bench_conv(sh, 1, 256, Ts[sh], 20, v, ctypes.byref(ms)))
-        row.append(f"v{v}={ms.value*1e3:.0f}us")
+        ph = (ctypes.c_double * 8)()
+        _lib.check(lib.sk_bench_conv(sh, 1, 256, Ts[sh], 20, v, ctypes.byref(ms), ph if STAMPS else None))
+        txt = f"v{v}={ms.value*1e3:.0f}us"
+        if STAMPS:
+            txt += " [cyc: issue %d | land+bar %d | kloop %d | bar+epi %d | bar %d | out %d | WG total %d]" % (ph[0], ph[1], ph[2], ph[3], ph[4], ph[5], ph[7])
+        row.append(txt)
     print(names[sh], " ".join(row), flush=True)

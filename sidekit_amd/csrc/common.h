@@ -57,9 +57,15 @@ __host__ __device__ inline uint16_t f32_to_bf16(float f) {
 }
 // ReLU that lets NaN through like torch.relu (fmaxf would swallow it)
 __device__ inline float relu_nan(float x) { return x < 0.f ? 0.f : x; }
+// device-side conversions use the hardware v_cvt_pk_bf16_f32 (round-to-nearest-even, NaN stays NaN): the integer
+// formulation above costs ~8 VALU per value, which made the conv epilogues VALU-bound (measured with in-kernel stamps)
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
 __device__ inline uint32_t pack_bf16x2(float lo, float hi) {
-  return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+  const f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
+__device__ inline float round_bf16(float x) { return (float)(__bf16)x; }
 
 template <typename T> struct elem;
 template <> struct elem<float> {

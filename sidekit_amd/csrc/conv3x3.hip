@@ -45,8 +45,11 @@ struct ConvCfg {
   static constexpr int WP = WIN + 2;             // staged input columns (zero column each side)
   static constexpr int CB = CK * EB;             // channel bytes staged per position
   static constexpr int PSTRIDE = CB + 16;        // +16 B: ds_read_b128 of 32 neighbouring positions is conflict-free
-  static constexpr int NPOS = RIN * WP;
-  static constexpr int LDS = (NPOS * PSTRIDE + 1023) / 1024 * 1024;  // whole 1-KiB LDS-DMA pieces
+  static constexpr int SPP = PSTRIDE / 16;                // 16-B slots per staged position
+  static constexpr int PPR = (WP * SPP + 63) / 64;        // 1-KiB LDS-DMA pieces per staged row
+  static constexpr int RS = PPR * 1024;                   // LDS row stride: rows start on a piece boundary, so a piece's
+                                                          // (row, column) decode is one scalar division + one lane-side /SPP
+  static constexpr int LDS = RIN * RS;
   static constexpr int KS = CB / 32;             // MFMA k-steps (32 B of k) per tap per chunk
   static constexpr int NCH = CIN / CK;           // channel chunks
   static constexpr int KTOT = NCH * TAPS * KS;   // k-steps per output-channel tile
@@ -78,13 +81,17 @@ void conv3x3_kernel(ConvArgs a) {
   const int hin_b = halve(a.lens.get(b), a.halvings_in);
   const int hout_b = (C::S == 2) ? ((hin_b + 1) >> 1) : hin_b;
   if (ho0 >= hout_b) return;  // nothing valid in this tile (its SE partial is never read)
+  auto stamp = [&](int k) {  // diagnostic build path only (a.stamps == nullptr in the product)
+    if (a.stamps && tid == 0) a.stamps[(size_t)blockIdx.x * 8 + k] = __builtin_amdgcn_s_memtime();
+  };
+  stamp(0);
 
   int base[C::MW];
 #pragma unroll
   for (int i = 0; i < C::MW; ++i) {
     const int m = (wm * C::MW + i) * 32 + r;
     const int ho = m / C::WOUT, wo = m % C::WOUT;
-    base[i] = ((ho * C::S) * C::WP + wo * C::S) * C::PSTRIDE + h * 16;
+    base[i] = (ho * C::S) * C::RS + (wo * C::S) * C::PSTRIDE + h * 16;
   }
   f32x16 acc[C::MW][C::NW];
 #pragma unroll
@@ -121,24 +128,26 @@ void conv3x3_kernel(ConvArgs a) {
     // stage the halo tile with LDS-DMA (global_load_lds_dwordx4: 64 lanes x 16 B land on 1 KiB of LDS, no VGPRs,
     // every piece in flight at once).  A lane whose slot is a pad slot or a zero-padding position reads the zero page
     // (measured: masking those lanes off and zero-filling with ds_write instead is 20 % slower).
-    constexpr int CPP = C::CB / 16, SPP = C::PSTRIDE / 16, NPIECE = C::LDS / 1024;
-#pragma unroll 2
+    constexpr int CPP = C::CB / 16, NPIECE = C::RIN * C::PPR;
     for (int it = (a.dbg & 4) ? NPIECE : wave; it < NPIECE; it += NWAVES) {
-      const int slot = it * 64 + lane;
-      const int pos = slot / SPP, cc = slot % SPP;
-      const int row = pos / C::WP, col = pos % C::WP;
-      const int hi = hi0 + row, wi = col - 1;
+      const int row = it / C::PPR, q = it % C::PPR;          // wave-uniform
+      const int hi = hi0 + row;
+      const bool rowok = hi >= 0 && hi < hin_b;
+      const unsigned char* rowbase = in + ((((size_t)b * a.Hin + hi) * C::WIN) * C::CIN + ch * C::CK) * C::EB;
+      const int slot = q * 64 + lane;
+      const int col = slot / C::SPP, cc = slot - col * C::SPP;
       const unsigned char* src = reinterpret_cast<const unsigned char*>(a.zeros);
-      if (cc < CPP && pos < C::NPOS && hi >= 0 && hi < hin_b && wi >= 0 && wi < C::WIN)
-        src = in + ((((size_t)b * a.Hin + hi) * C::WIN + wi) * C::CIN + ch * C::CK) * C::EB + cc * 16;
+      if (rowok && cc < CPP && col >= 1 && col <= C::WIN) src = rowbase + (col - 1) * (C::CIN * C::EB) + cc * 16;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(smem + it * 1024), 16, 0, 0);
     }
+    stamp(1);
     __syncthreads();
+    stamp(2);
     auto xaddr = [&](int i, int kk) {
       const int t = kk / C::KS, ks = kk % C::KS;
       const int tap = (C::TAPS == 9) ? t : 4;
-      return smem + base[i] + ((tap / 3) * C::WP + tap % 3) * C::PSTRIDE + ks * 32;
+      return smem + base[i] + (tap / 3) * C::RS + (tap % 3) * C::PSTRIDE + ks * 32;
     };
     uint4 xc[C::MW], xn[C::MW];
 #pragma unroll
@@ -183,6 +192,7 @@ void conv3x3_kernel(ConvArgs a) {
     if constexpr (C::EB == 2) return bf16_to_f32(*reinterpret_cast<const uint16_t*>(smem + m * OPS + c * 2));
     else return *reinterpret_cast<const float*>(smem + m * OPS + c * 4);
   };
+  stamp(3);
 #pragma unroll
   for (int j = 0; j < C::NW; ++j) {
     __syncthreads();  // every wave is done with the halo tile (j == 0) / the previous sub-tile has been copied out
@@ -223,7 +233,7 @@ void conv3x3_kernel(ConvArgs a) {
           float x = acc[i][j][4 * g + q] * sc[g][q] + sh[g][q];
           if (a.gate) x *= gt[g][q];
           else if (a.relu) x = relu_nan(x);
-          if constexpr (C::EB == 2) x = bf16_to_f32(f32_to_bf16(x));  // what is stored (and what the next conv reads)
+          if constexpr (C::EB == 2) x = round_bf16(x);  // what is stored (and what the next conv reads)
           v[q] = x;
           ssum[4 * g + q] += valid ? x : 0.f;
         }
@@ -246,7 +256,9 @@ void conv3x3_kernel(ConvArgs a) {
           *reinterpret_cast<float4*>(sp + 8 * g) = make_float4(ssum[4 * g], ssum[4 * g + 1], ssum[4 * g + 2], ssum[4 * g + 3]);
       }
     }
+    if (j == 0) stamp(4);
     __syncthreads();  // out sub-tile complete
+    if (j == 0) stamp(5);
     if (a.se_part && tid < NC) {
       // edge sums for the next conv's zero padding: a tap shifted by (dh, dw) misses one border row and/or column
       const int c = tid, cg = j * NC + c, rows_valid = mvalid / C::WOUT, hl = hout_b - 1;
@@ -299,6 +311,7 @@ void conv3x3_kernel(ConvArgs a) {
         *reinterpret_cast<uint4*>(out + ((gpos0 + m) * C::COUT + j * NC) * C::EB + cc * 16) = v;
       }
     }
+    if (j == C::NW - 1) stamp(6);
   }
 }
 

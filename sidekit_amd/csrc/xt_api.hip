@@ -931,7 +931,7 @@ int xt_get_profile(xt_handle* h, double* ms, int64_t* launches, int32_t reset) {
 
 // Kernel-level timing harness for tuning (diagnostic; not used by the product path): runs one trunk
 // convolution shape `iters` times on zero-initialised buffers and returns the mean device time.
-int sk_bench_conv(int32_t shape, int32_t dtype, int32_t B, int32_t T, int32_t iters, int32_t variant, float* ms_out) {
+int sk_bench_conv(int32_t shape, int32_t dtype, int32_t B, int32_t T, int32_t iters, int32_t variant, float* ms_out, double* phase_cycles) {
   SK_CHECK(ms_out && B > 0 && T > 0 && iters > 0, SK_EARG, "sk_bench_conv: bad arguments");
   ConvGeom g;
   const int dt = dtype == XT_BF16 ? DT_BF16 : DT_F32;
@@ -948,6 +948,19 @@ int sk_bench_conv(int32_t shape, int32_t dtype, int32_t B, int32_t T, int32_t it
   memset(&a, 0, sizeof(a));
   a.in = in; a.wpack = w; a.scale = sc; a.shift = sh; a.out = out; a.se_part = nullptr; a.zeros = zeros;
   a.lens = Lens{nullptr, T}; a.halvings_in = 0; a.B = B; a.Hin = hin; a.Hout = hout; a.relu = 1; a.dbg = variant & 7;
+  const int nblk = B * cdiv(hout, g.th);
+  unsigned long long* stamps = nullptr;
+  float *gate = nullptr; void* scut = nullptr; float *colp = nullptr, *edge = nullptr;
+  if (variant & 8) {   // statistics-mode epilogue
+    SK_HIP(hipMalloc((void**)&colp, (size_t)nblk * 2 * g.cout * 4)); SK_HIP(hipMalloc((void**)&edge, (size_t)B * 6 * g.cout * 4));
+    a.se_part = se; a.col_part = colp; a.edge = edge;
+  }
+  if (variant & 16) {  // residual-mode epilogue
+    SK_HIP(hipMalloc((void**)&gate, (size_t)B * g.cout * 4)); SK_HIP(hipMalloc(&scut, out_b));
+    SK_HIP(hipMemset(gate, 0, (size_t)B * g.cout * 4)); SK_HIP(hipMemset(scut, 0, out_b));
+    a.gate = gate; a.shortcut = scut;
+  }
+  if (phase_cycles) { SK_HIP(hipMalloc((void**)&stamps, (size_t)nblk * 64)); SK_HIP(hipMemset(stamps, 0, (size_t)nblk * 64)); a.stamps = stamps; }
   hipEvent_t e0, e1;
   SK_HIP(hipEventCreate(&e0)); SK_HIP(hipEventCreate(&e1));
   for (int i = 0; i < 3; ++i) SK_TRY(launch_conv(shape, dt, a, nullptr));
@@ -957,6 +970,21 @@ int sk_bench_conv(int32_t shape, int32_t dtype, int32_t B, int32_t T, int32_t it
   SK_HIP(hipEventSynchronize(e1));
   SK_HIP(hipEventElapsedTime(ms_out, e0, e1));
   *ms_out /= iters;
+  if (phase_cycles) {  // mean cycles between consecutive stamps over all workgroups of the last launch; [7] = whole workgroup
+    std::vector<unsigned long long> hs((size_t)nblk * 8);
+    SK_HIP(hipMemcpy(hs.data(), stamps, hs.size() * 8, hipMemcpyDeviceToHost));
+    for (int k = 0; k < 8; ++k) phase_cycles[k] = 0;
+    int n = 0;
+    for (int i = 0; i < nblk; ++i) {
+      if (!hs[(size_t)i * 8 + 6]) continue;
+      for (int k = 0; k < 6; ++k) phase_cycles[k] += (double)(hs[(size_t)i * 8 + k + 1] - hs[(size_t)i * 8 + k]);
+      phase_cycles[7] += (double)(hs[(size_t)i * 8 + 6] - hs[(size_t)i * 8]);
+      ++n;
+    }
+    for (int k = 0; k < 8; ++k) phase_cycles[k] /= (n ? n : 1);
+    (void)hipFree(stamps);
+  }
+  if (colp) (void)hipFree(colp); if (edge) (void)hipFree(edge); if (gate) (void)hipFree(gate); if (scut) (void)hipFree(scut);
   (void)hipFree(in); (void)hipFree(out); (void)hipFree(w); (void)hipFree(zeros); (void)hipFree(sc); (void)hipFree(sh); (void)hipFree(se);
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   return SK_OK;
