@@ -69,6 +69,21 @@ struct LoadPower {
   }
 };
 
+__device__ inline float gemm_epilogue(const GemmArgs& g, float v, int m, int n) {
+  if (g.bias) v += g.bias[n];
+  if (g.rowbias) v += g.rowbias[(long)(m / g.rows_per_group) * g.N + n];
+  const float sc = g.scale ? g.scale[n] : 1.f, sh = g.scale ? g.shift[n] : 0.f;
+  switch (g.act) {
+    case ACT_RELU: v = relu_nan(v); break;
+    case ACT_LRELU02: v = v > 0.f ? v : 0.2f * v; break;
+    case ACT_RELU_BN_TANH: v = tanhf(relu_nan(v) * sc + sh); break;
+    case ACT_LOG_EPS: v = logf(v + 1e-6f); break;
+    default: break;
+  }
+  if (g.act != ACT_RELU_BN_TANH) v = v * sc + sh;
+  return v * g.alpha;
+}
+
 template <class LA>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) float As[BM * LDT];
@@ -93,16 +108,19 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   f32x16 acc;
 #pragma unroll
   for (int q = 0; q < 16; ++q) acc[q] = 0.f;
-  const int nk = (g.K + BK - 1) / BK;
-  fetch(0);
-  for (int kt = 0; kt < nk; ++kt) {
+  // split-K: blockIdx.z owns k-tiles [kt0, kt1)
+  const int nk_all = (g.K + BK - 1) / BK;
+  const int per = (nk_all + g.ksplit - 1) / g.ksplit;
+  const int kt0 = blockIdx.z * per, kt1 = (kt0 + per < nk_all) ? kt0 + per : nk_all;
+  if (kt0 < kt1) fetch(kt0 * BK);
+  for (int kt = kt0; kt < kt1; ++kt) {
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       *reinterpret_cast<float4*>(&As[(srow + q * 32) * LDT + sk4]) = ra[q];
       *reinterpret_cast<float4*>(&Ws[(srow + q * 32) * LDT + sk4]) = rw[q];
     }
     __syncthreads();
-    if (kt + 1 < nk) fetch((kt + 1) * BK);
+    if (kt + 1 < kt1) fetch((kt + 1) * BK);
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 8) {
       const float4 a = *reinterpret_cast<const float4*>(&As[(wm * 32 + r) * LDT + kk + 4 * h]);
@@ -117,31 +135,41 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   // epilogue: D[row = (q&3) + 8*(q>>2) + 4*h][col = r]
   const int n = n0 + wn * 32 + r;
   if (n >= g.N) return;
-  const float bias = g.bias ? g.bias[n] : 0.f;
-  const float sc = g.scale ? g.scale[n] : 1.f, sh = g.scale ? g.shift[n] : 0.f;
+  if (g.ksplit > 1) {  // raw partial sums; gemm_splitk_epilogue_kernel adds them in slice order and applies the epilogue
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int m = m0 + wm * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+      if (m < g.M) g.splitk_ws[((long)blockIdx.z * g.M + m) * g.N + n] = acc[q];
+    }
+    return;
+  }
 #pragma unroll
   for (int q = 0; q < 16; ++q) {
     const int m = m0 + wm * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
-    if (m >= g.M) continue;
-    float v = acc[q] + bias;
-    if (g.rowbias) v += g.rowbias[(long)(m / g.rows_per_group) * g.N + n];
-    switch (g.act) {
-      case ACT_RELU: v = relu_nan(v); break;
-      case ACT_LRELU02: v = v > 0.f ? v : 0.2f * v; break;
-      case ACT_RELU_BN_TANH: v = tanhf(relu_nan(v) * sc + sh); break;
-      case ACT_LOG_EPS: v = logf(v + 1e-6f); break;
-      default: break;
-    }
-    if (g.act != ACT_RELU_BN_TANH) v = v * sc + sh;
-    g.C[(long)m * g.ldc + n] = v * g.alpha;
+    if (m < g.M) g.C[(long)m * g.ldc + n] = gemm_epilogue(g, acc[q], m, n);
   }
 }
 
-int launch_gemm(const GemmArgs& g, hipStream_t s) {
+__global__ __launch_bounds__(256) void gemm_splitk_epilogue_kernel(GemmArgs g) {
+  const long i = blockIdx.x * 256L + threadIdx.x;
+  if (i >= (long)g.M * g.N) return;
+  const int m = (int)(i / g.N), n = (int)(i % g.N);
+  float v = 0.f;
+  for (int z = 0; z < g.ksplit; ++z) v += g.splitk_ws[((long)z * g.M + m) * g.N + n];
+  g.C[(long)m * g.ldc + n] = gemm_epilogue(g, v, m, n);
+}
+
+int launch_gemm(const GemmArgs& g_in, hipStream_t s) {
+  GemmArgs g = g_in;
+  g.ksplit = 1;
+  if (g.splitk_ws && g.M <= 512 && g.K >= 1024) {
+    const int nk = (g.K + BK - 1) / BK;
+    g.ksplit = nk / 8 < 32 ? (nk / 8 > 1 ? nk / 8 : 1) : 32;   // >= 8 k-tiles per slice, at most 32 slices
+  }
   SK_CHECK(g.M > 0 && g.N > 0 && g.K > 0, SK_EARG, "gemm: empty problem %dx%dx%d", g.M, g.N, g.K);
   SK_CHECK(g.K % 4 == 0 && g.ldw % 4 == 0, SK_EARG, "gemm: K=%d / ldw=%ld must be multiples of 4", g.K, g.ldw);
   SK_CHECK(g.a_mode != A_PLAIN || (g.lda % 4 == 0 && g.kc % 4 == 0), SK_EARG, "gemm: lda/kc alignment");
-  dim3 grid(cdiv(g.M, BM), cdiv(g.N, BN));
+  dim3 grid(cdiv(g.M, BM), cdiv(g.N, BN), g.ksplit);
   switch (g.a_mode) {
     case A_PLAIN: hipLaunchKernelGGL(gemm_kernel<LoadPlain>, grid, dim3(256), 0, s, g); break;
     case A_FRAMES: hipLaunchKernelGGL(gemm_kernel<LoadFrames>, grid, dim3(256), 0, s, g); break;
@@ -149,6 +177,10 @@ int launch_gemm(const GemmArgs& g, hipStream_t s) {
     default: set_error("gemm: bad a_mode %d", g.a_mode); return SK_EARG;
   }
   SK_HIP(hipGetLastError());
+  if (g.ksplit > 1) {
+    hipLaunchKernelGGL(gemm_splitk_epilogue_kernel, dim3((unsigned)(((long)g.M * g.N + 255) / 256)), dim3(256), 0, s, g);
+    SK_HIP(hipGetLastError());
+  }
   return SK_OK;
 }
 

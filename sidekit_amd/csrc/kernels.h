@@ -98,6 +98,9 @@ struct GemmArgs {
   const float* scale;   // [N] or null: applied after the activation (BatchNorm that follows it)
   const float* shift;   // [N]
   float alpha;          // final multiplier
+  // split-K for skinny problems (M <= 512, K large: 16 workgroups would otherwise walk thousands of k-steps serially):
+  float* splitk_ws;     // [ksplit][M][N] partial sums, or null (no split)
+  int ksplit;           // set by launch_gemm
 };
 GemmArgs gemm_args();   // zero-initialised, alpha = 1
 int launch_gemm(const GemmArgs& g, hipStream_t s);

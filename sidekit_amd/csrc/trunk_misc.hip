@@ -7,7 +7,7 @@ namespace sk {
 
 // ---- stem: relu(bn(conv3x3(1->32, pad 1))) on the logical (B,1,H=T,W=80) image -----------------
 // One workgroup = TT time rows x 80 freqs; the (TT+2) x 82 input patch goes through LDS, every
-// thread produces one position x 32 channels (288 FMAs) and writes 64 B (bf16) / 128 B (f32).
+// thread produces one position x 32 channels (288 FMAs, weights as SGPR operands) and writes 64 B (bf16) / 128 B (f32).
 constexpr int STEM_TT = 16;
 constexpr int STEM_W = 80;
 
@@ -17,14 +17,11 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ fea
                                                    const float* __restrict__ shift, unsigned char* __restrict__ out,
                                                    Lens lens, int T) {
   __shared__ float patch[(STEM_TT + 2) * (STEM_W + 2)];
-  __shared__ float ws[32 * 9 + 64];
   const int tid = threadIdx.x;
   const int tiles = (T + STEM_TT - 1) / STEM_TT;
   const int b = blockIdx.x / tiles, t0 = (blockIdx.x % tiles) * STEM_TT;
   const int tb = lens.get(b);
   if (t0 >= tb) return;
-  for (int i = tid; i < 32 * 9; i += 256) ws[i] = w[i];
-  if (tid < 32) { ws[288 + tid] = scale[tid]; ws[320 + tid] = shift[tid]; }
   for (int i = tid; i < (STEM_TT + 2) * (STEM_W + 2); i += 256) {
     const int row = i / (STEM_W + 2), col = i % (STEM_W + 2);
     const int t = t0 - 1 + row, f = col - 1;
@@ -48,8 +45,8 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ fea
       for (int c = 0; c < 8; ++c) {
         float s = 0.f;
 #pragma unroll
-        for (int q = 0; q < 9; ++q) s = fmaf(ws[(c0 + c) * 9 + q], x[q], s);
-        v[c] = relu_nan(s * ws[288 + c0 + c] + ws[320 + c0 + c]);
+        for (int q = 0; q < 9; ++q) s = fmaf(w[(c0 + c) * 9 + q], x[q], s);   // uniform index: the weights arrive by scalar loads
+        v[c] = relu_nan(s * scale[c0 + c] + shift[c0 + c]);
       }
       if constexpr (EB == 2) {
         *reinterpret_cast<uint4*>(op + c0 * 2) =

@@ -99,7 +99,7 @@ struct xt_handle {
 
   // workspace
   int max_batch = 0; int64_t max_samples = 0;
-  DevBuf ws_S, ws_feat, ws_act[4], ws_se, ws_col, ws_edge, ws_gate, ws_ctx, ws_rb, ws_h, ws_e, ws_pooled, ws_pre, ws_emb, ws_int, ws_ragged;
+  DevBuf ws_S, ws_feat, ws_act[4], ws_se, ws_col, ws_edge, ws_splitk, ws_gate, ws_ctx, ws_rb, ws_h, ws_e, ws_pooled, ws_pre, ws_emb, ws_int, ws_ragged;
   // pinned staging ring for per-utterance integers
   static constexpr int RING = 4;
   int* ring_host[RING] = {nullptr, nullptr, nullptr, nullptr};
@@ -608,7 +608,7 @@ static int half_from_feats(xt_handle* h, const float* feats, long sb, long sf, l
   SK_TRY(launch_mean_std(X, xbf, D, D, rs, (float*)h->ws_ctx.p, B, st));
   GemmArgs c = gemm_args();  // context term of attention.0: W1[:, 2560:] . [mean | std] + bias, once per utterance
   c.A = h->ws_ctx.p; c.lda = 2 * D; c.a_rows = B; c.W = h->att_w1c; c.ldw = 2 * D; c.C = (float*)h->ws_rb.p; c.ldc = 128;
-  c.M = B; c.N = 128; c.K = 2 * D; c.bias = h->att_b1;
+  c.M = B; c.N = 128; c.K = 2 * D; c.bias = h->att_b1; c.splitk_ws = (float*)h->ws_splitk.p;
   SK_TRY(launch_gemm(c, st));
   GemmArgs g1 = gemm_args();  // attention.0 on x + ReLU + BatchNorm1d + tanh
   g1.A = X; g1.a_bf16 = xbf; g1.lda = D; g1.a_rows = R; g1.W = h->att_w1x; g1.ldw = D; g1.C = (float*)h->ws_h.p; g1.ldc = 128;
@@ -624,6 +624,7 @@ static int half_from_feats(xt_handle* h, const float* feats, long sb, long sf, l
   GemmArgs e = gemm_args();  // lin_be + bn_be (xvector.py:578-581)
   e.A = h->ws_pooled.p; e.lda = 2 * D; e.a_rows = B; e.W = h->emb_w; e.ldw = 2 * D; e.C = (float*)h->ws_pre.p;
   e.ldc = h->cfg.emb_dim; e.M = B; e.N = h->cfg.emb_dim; e.K = 2 * D; e.scale = h->emb_scale; e.shift = h->emb_shift;
+  if (h->cfg.emb_dim <= 256) e.splitk_ws = (float*)h->ws_splitk.p;
   SK_TRY(launch_gemm(e, st));
   return tail(h, B, d_emb, d_logits, st);
 }
@@ -654,6 +655,7 @@ static int tdnn_from_rows(xt_handle* h, const float* rows, const BatchMeta& m, f
   GemmArgs e = gemm_args();  // linear6 (xvector.py:489-491)
   e.A = h->ws_pooled.p; e.lda = 3072; e.a_rows = m.B; e.W = h->emb_w; e.ldw = 3072; e.C = (float*)h->ws_pre.p; e.ldc = h->cfg.emb_dim;
   e.M = m.B; e.N = h->cfg.emb_dim; e.K = 3072; e.bias = h->emb_bias;
+  if (h->cfg.emb_dim <= 256) e.splitk_ws = (float*)h->ws_splitk.p;
   SK_TRY(launch_gemm(e, st));
   return tail(h, m.B, d_emb, h->cfg.loss == XT_LOSS_AAM ? d_logits : nullptr, st);
 }
@@ -741,7 +743,7 @@ int xt_create(const xt_config* cfg, xt_handle** out) {
 int xt_destroy(xt_handle* h) {
   if (!h) return SK_OK;
   for (void* p : h->dev_allocs) (void)hipFree(p);
-  DevBuf* bufs[] = {&h->ws_S, &h->ws_feat, &h->ws_act[0], &h->ws_act[1], &h->ws_act[2], &h->ws_act[3], &h->ws_se, &h->ws_col, &h->ws_edge, &h->ws_gate,
+  DevBuf* bufs[] = {&h->ws_S, &h->ws_feat, &h->ws_act[0], &h->ws_act[1], &h->ws_act[2], &h->ws_act[3], &h->ws_se, &h->ws_col, &h->ws_edge, &h->ws_splitk, &h->ws_gate,
                     &h->ws_ctx, &h->ws_rb, &h->ws_h, &h->ws_e, &h->ws_pooled, &h->ws_pre, &h->ws_emb, &h->ws_int, &h->ws_ragged};
   for (DevBuf* b : bufs) b->release();
   for (auto& kv : h->taps) kv.second.buf.release();
@@ -815,6 +817,7 @@ int xt_reserve(xt_handle* h, int32_t max_batch, int64_t max_samples) {
   }
   const size_t E = (size_t)h->cfg.emb_dim;
   SK_TRY(h->ws_pre.ensure(B * E * 4));
+  SK_TRY(h->ws_splitk.ensure((size_t)32 * (B < 512 ? B : 512) * 256 * 4));  // split-K partials of the skinny GEMMs (N <= 256)
   SK_TRY(h->ws_emb.ensure(B * E * 4));
   if (h->cfg.arch == XT_ARCH_HALFRESNET34) {
     const size_t EB = h->cfg.dtype == XT_BF16 ? 2 : 4;
