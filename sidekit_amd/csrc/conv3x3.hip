@@ -60,8 +60,8 @@ struct ConvCfg {
 
 // second launch-bound = waves per SIMD: two workgroups per CU whenever two halo tiles fit the LDS, which caps the
 // kernel at 256 registers (VGPR + AGPR) per lane
-template <class C>
-__global__ __launch_bounds__(C::WM * C::WN * 64, (C::MW * C::NW <= 5 && 160 * 1024 / C::LDS * C::WM * C::WN >= 8) ? 2 : 1)
+template <class C, bool SC>
+__global__ __launch_bounds__(C::WM * C::WN * 64, (!SC && C::MW * C::NW <= 5 && 160 * 1024 / C::LDS * C::WM * C::WN >= 8) ? 2 : 1)
 void conv3x3_kernel(ConvArgs a) {
   using T = typename C::T;
   constexpr int NWAVES = C::WM * C::WN, NTHREADS = NWAVES * 64;
@@ -94,12 +94,16 @@ void conv3x3_kernel(ConvArgs a) {
     base[i] = (ho * C::S) * C::RS + (wo * C::S) * C::PSTRIDE + h * 16;
   }
   f32x16 acc[C::MW][C::NW];
+  f32x16 acc_sc[SC ? C::MW : 1][SC ? C::NW : 1];  // fused 1x1 shortcut: centre tap only
 #pragma unroll
   for (int i = 0; i < C::MW; ++i)
 #pragma unroll
     for (int j = 0; j < C::NW; ++j)
 #pragma unroll
-      for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+      for (int q = 0; q < 16; ++q) {
+        acc[i][j][q] = 0.f;
+        if constexpr (SC) acc_sc[i][j][q] = 0.f;
+      }
 
   // Output-channel tile of (wave column wn, repeat j) = j*WN + wn: for a fixed j the workgroup's WN*32 channels are
   // contiguous, so the staged out tile leaves as contiguous NHWC rows.  Fragment address = wave-uniform (SGPR)
@@ -123,6 +127,17 @@ void conv3x3_kernel(ConvArgs a) {
     for (int d = 0; d < PD; ++d)
 #pragma unroll
       for (int j = 0; j < C::NW; ++j) wq[d][j] = wload(j, ch * NK + d);
+    uint4 wsc[SC ? C::KS : 1][SC ? C::NW : 1];
+    if constexpr (SC) {
+      const unsigned char* scb = reinterpret_cast<const unsigned char*>(a.sc_wpack);
+#pragma unroll
+      for (int ks = 0; ks < C::KS; ++ks)
+#pragma unroll
+        for (int j = 0; j < C::NW; ++j) {
+          const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane(((j * C::WN + wn) * (C::NCH * C::KS) + ch * C::KS + ks) * 1024);
+          wsc[ks][j] = *reinterpret_cast<const uint4*>(scb + soff + lane16);
+        }
+    }
     __builtin_amdgcn_sched_barrier(0);  // keep the loads up here: the scheduler otherwise sinks them next to their use
     if (ch) __syncthreads();
     // stage the halo tile with LDS-DMA (global_load_lds_dwordx4: 64 lanes x 16 B land on 1 KiB of LDS, no VGPRs,
@@ -171,6 +186,14 @@ void conv3x3_kernel(ConvArgs a) {
       for (int i = 0; i < C::MW; ++i)
 #pragma unroll
         for (int j = 0; j < C::NW; ++j) mma_step<T>(acc[i][j], wf[j], xc[i]);
+      if constexpr (SC) {
+        if (kk / C::KS == 4) {  // centre tap: the strided 1x1 shortcut sees exactly these activation fragments
+#pragma unroll
+          for (int i = 0; i < C::MW; ++i)
+#pragma unroll
+            for (int j = 0; j < C::NW; ++j) mma_step<T>(acc_sc[i][j], wsc[kk % C::KS][j], xc[i]);
+        }
+      }
 #pragma unroll
       for (int i = 0; i < C::MW; ++i) xc[i] = xn[i];
     }
@@ -182,7 +205,6 @@ void conv3x3_kernel(ConvArgs a) {
   //   residual   (conv2 of a block)            -> * gate[b][c] + shortcut -> ReLU -> store
   // The tile is transposed through the (now consumed) LDS halo buffer and leaves as whole 1-KiB, 16-B-per-lane NHWC
   // rows (direct 8-B stores ran at 2.9 TB/s); the shortcut rows are read the same way in the residual form.
-  unsigned char* out = reinterpret_cast<unsigned char*>(a.out);
   constexpr int NC = C::WN * 32;                // channels of one out sub-tile
   constexpr int OPS = NC * C::EB + 16;          // out-tile position stride in LDS (padded against bank conflicts)
   static_assert(C::MT * OPS <= C::LDS, "out tile must fit the consumed input buffer");
@@ -193,6 +215,8 @@ void conv3x3_kernel(ConvArgs a) {
     else return *reinterpret_cast<const float*>(smem + m * OPS + c * 4);
   };
   stamp(3);
+  // one output stream: (accumulators, BN scale/shift, destination, epilogue form)
+  auto emit = [&](auto& accv, const float* scale, const float* shift, unsigned char* out, const float* gate, float* se_part, bool relu) {
 #pragma unroll
   for (int j = 0; j < C::NW; ++j) {
     __syncthreads();  // every wave is done with the halo tile (j == 0) / the previous sub-tile has been copied out
@@ -202,7 +226,7 @@ void conv3x3_kernel(ConvArgs a) {
     constexpr int NIT = (C::MT * CPR + NTHREADS - 1) / NTHREADS;   // copy-out iterations per thread
     const unsigned char* scut = reinterpret_cast<const unsigned char*>(a.shortcut);
     uint4 sreg[NIT];
-    if (a.gate) {
+    if (gate) {
 #pragma unroll
       for (int q = 0; q < NIT; ++q) {
         const int idx = tid + q * NTHREADS, m = idx / CPR, cc = idx % CPR;
@@ -216,9 +240,9 @@ void conv3x3_kernel(ConvArgs a) {
     f32x4 sc[4], sh[4], gt[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      sc[g] = *reinterpret_cast<const f32x4*>(a.scale + nbase + 8 * g + 4 * h);
-      sh[g] = *reinterpret_cast<const f32x4*>(a.shift + nbase + 8 * g + 4 * h);
-      if (a.gate) gt[g] = *reinterpret_cast<const f32x4*>(a.gate + (size_t)b * C::COUT + nbase + 8 * g + 4 * h);
+      sc[g] = *reinterpret_cast<const f32x4*>(scale + nbase + 8 * g + 4 * h);
+      sh[g] = *reinterpret_cast<const f32x4*>(shift + nbase + 8 * g + 4 * h);
+      if (gate) gt[g] = *reinterpret_cast<const f32x4*>(gate + (size_t)b * C::COUT + nbase + 8 * g + 4 * h);
     }
 #pragma unroll
     for (int i = 0; i < C::MW; ++i) {
@@ -230,9 +254,9 @@ void conv3x3_kernel(ConvArgs a) {
         float v[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          float x = acc[i][j][4 * g + q] * sc[g][q] + sh[g][q];
-          if (a.gate) x *= gt[g][q];
-          else if (a.relu) x = relu_nan(x);
+          float x = accv[i][j][4 * g + q] * sc[g][q] + sh[g][q];
+          if (gate) x *= gt[g][q];
+          else if (relu) x = relu_nan(x);
           if constexpr (C::EB == 2) x = round_bf16(x);  // what is stored (and what the next conv reads)
           v[q] = x;
           ssum[4 * g + q] += valid ? x : 0.f;
@@ -241,7 +265,7 @@ void conv3x3_kernel(ConvArgs a) {
         else *reinterpret_cast<float4*>(lp + 8 * g * 4) = make_float4(v[0], v[1], v[2], v[3]);
       }
     }
-    if (a.se_part) {
+    if (se_part) {
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         float s = ssum[q];
@@ -250,7 +274,7 @@ void conv3x3_kernel(ConvArgs a) {
         ssum[q] = s;
       }
       if (r == 0) {
-        float* sp = a.se_part + (((size_t)b * tiles + tile) * C::WM + wm) * C::COUT + nbase + 4 * h;
+        float* sp = se_part + (((size_t)b * tiles + tile) * C::WM + wm) * C::COUT + nbase + 4 * h;
 #pragma unroll
         for (int g = 0; g < 4; ++g)
           *reinterpret_cast<float4*>(sp + 8 * g) = make_float4(ssum[4 * g], ssum[4 * g + 1], ssum[4 * g + 2], ssum[4 * g + 3]);
@@ -259,7 +283,7 @@ void conv3x3_kernel(ConvArgs a) {
     if (j == 0) stamp(4);
     __syncthreads();  // out sub-tile complete
     if (j == 0) stamp(5);
-    if (a.se_part && tid < NC) {
+    if (se_part && tid < NC) {
       // edge sums for the next conv's zero padding: a tap shifted by (dh, dw) misses one border row and/or column
       const int c = tid, cg = j * NC + c, rows_valid = mvalid / C::WOUT, hl = hout_b - 1;
       float c0 = 0.f, cl = 0.f;
@@ -293,7 +317,7 @@ void conv3x3_kernel(ConvArgs a) {
         const int idx = tid + q * NTHREADS, m = idx / CPR, cc = idx % CPR;
         if (idx >= mvalid * CPR) break;
         uint4 v = *reinterpret_cast<const uint4*>(smem + m * OPS + cc * 16);
-        if (a.gate) {
+        if (gate) {
           const uint4 s = sreg[q];
           if constexpr (C::EB == 2) {
             const uint32_t vv[4] = {v.x, v.y, v.z, v.w}, ss[4] = {s.x, s.y, s.z, s.w};
@@ -311,15 +335,26 @@ void conv3x3_kernel(ConvArgs a) {
         *reinterpret_cast<uint4*>(out + ((gpos0 + m) * C::COUT + j * NC) * C::EB + cc * 16) = v;
       }
     }
-    if (j == C::NW - 1) stamp(6);
   }
+  };
+  emit(acc, a.scale, a.shift, reinterpret_cast<unsigned char*>(a.out), a.gate, a.se_part, a.relu != 0);
+  if constexpr (SC) emit(acc_sc, a.sc_scale, a.sc_shift, reinterpret_cast<unsigned char*>(a.sc_out), nullptr, nullptr, false);
+  stamp(6);
 }
 
 template <class C>
 static int launch_cfg(const ConvArgs& a, hipStream_t st) {
   const int tiles = cdiv(a.Hout, C::TH);
   dim3 grid((unsigned)(a.B * tiles));
-  hipLaunchKernelGGL(conv3x3_kernel<C>, grid, dim3(C::WM * C::WN * 64), 0, st, a);
+  if constexpr (C::TAPS == 9 && C::NW == 1) {
+    if (a.sc_wpack) {
+      hipLaunchKernelGGL((conv3x3_kernel<C, true>), grid, dim3(C::WM * C::WN * 64), 0, st, a);
+      SK_HIP(hipGetLastError());
+      return SK_OK;
+    }
+  }
+  SK_CHECK(!a.sc_wpack, SK_EARG, "this convolution shape has no fused-shortcut form");
+  hipLaunchKernelGGL((conv3x3_kernel<C, false>), grid, dim3(C::WM * C::WN * 64), 0, st, a);
   SK_HIP(hipGetLastError());
   return SK_OK;
 }
@@ -353,7 +388,7 @@ using F_L4   = ConvCfg<float, 256, 256, 1, 10, 16, 1, 4, 5, 2, 128, 9>;
 template <class C>
 static void fill_geom(ConvGeom& g) {
   g.cin = C::CIN; g.cout = C::COUT; g.stride = C::S; g.win = C::WIN; g.th = C::TH; g.wm = C::WM;
-  g.ck = C::CK; g.taps = C::TAPS; g.ks = C::KS; g.eb = C::EB;
+  g.ck = C::CK; g.taps = C::TAPS; g.ks = C::KS; g.eb = C::EB; g.nw = C::NW;
 }
 
 #define SK_CONV_CASES(X) \

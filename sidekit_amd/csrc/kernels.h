@@ -24,6 +24,9 @@ struct ConvArgs {
   float* col_part;     // [B][tiles][2][COUT]  first / last column sums over the tile's valid rows
   float* edge;         // [B][6][COUT]         first-row sum, last-row sum, corners (0,0) (0,W-1) (last,0) (last,W-1)
   // -- residual mode (conv2 of a BasicBlock; gate != nullptr): out = relu(bn(conv) * gate[b][c] + shortcut)  (res_net.py:316-319)
+  // -- fused 1x1 shortcut (first block of a layer; sc_wpack != nullptr): bn(conv1x1_stride(x)) from the centre tap of
+  //    the halo tile this convolution has staged anyway (res_net.py:301-307), written to sc_out
+  const void* sc_wpack; const float* sc_scale; const float* sc_shift; void* sc_out;
   const float* gate;   // [B][COUT]
   const void* shortcut;  // NHWC, same shape and type as out
   const void* zeros;   // >= 16 zero bytes in device memory (source of the conv zero padding)
@@ -35,7 +38,7 @@ struct ConvArgs {
   int dbg;             // diagnostics only (sk_bench_conv): bit0 skip stores, bit1 skip MFMA loop, bit2 skip staging
 };
 
-struct ConvGeom { int cin, cout, stride, win, th, wm, ck, taps, ks, eb; };
+struct ConvGeom { int cin, cout, stride, win, th, wm, ck, taps, ks, eb, nw; };
 
 int conv_geom(int shape, int dtype, ConvGeom* g);
 int launch_conv(int shape, int dtype, const ConvArgs& a, hipStream_t st);

@@ -570,13 +570,16 @@ static int half_from_feats(xt_handle* h, const float* feats, long sb, long sf, l
     a.in = X; a.wpack = b.c1.wpack; a.scale = b.c1.scale; a.shift = b.c1.shift; a.out = O1;
     a.se_part = (float*)h->ws_se.p; a.col_part = (float*)h->ws_col.p; a.edge = (float*)h->ws_edge.p;
     a.halvings_in = lin; a.Hin = Hl[lin]; a.Hout = Hl[li]; a.relu = 1;
+    // shortcut rides on conv1's centre tap where that costs no occupancy (the stride-2 shapes already run one workgroup per CU)
+    const bool fuse_sc = first && b.c1.g.stride == 2 && b.c1.g.nw == 1 && b.sc.g.ck == b.c1.g.ck;
+    if (fuse_sc) { a.sc_wpack = b.sc.wpack; a.sc_scale = b.sc.scale; a.sc_shift = b.sc.shift; a.sc_out = SC; }
     { ProfScope ps(h, b.c1.shape, st); SK_TRY(launch_conv(b.c1.shape, dt, a, st)); }
-    const void* shortcut = X;
-    if (first) {  // 1x1 conv (stride s) + bn on the block input
+    a.sc_wpack = nullptr;
+    const void* shortcut = first ? SC : X;
+    if (first && !fuse_sc) {  // 1x1 conv (stride s) + bn on the block input
       a.wpack = b.sc.wpack; a.scale = b.sc.scale; a.shift = b.sc.shift; a.out = SC;
       a.se_part = nullptr; a.col_part = nullptr; a.edge = nullptr; a.relu = 0;
       { ProfScope ps(h, b.sc.shape, st); SK_TRY(launch_conv(b.sc.shape, dt, a, st)); }
-      shortcut = SC;
     }
     {  // SE gate, known before conv2 runs (linearity of the plane mean in O1)
       SeArgs se;
