@@ -66,7 +66,7 @@ void conv3x3_kernel(ConvArgs a) {
   using T = typename C::T;
   constexpr int NWAVES = C::WM * C::WN, NTHREADS = NWAVES * 64;
   static_assert(NWAVES == 2 || NWAVES == 4, "two or four waves per workgroup");
-  static_assert(C::NT == C::COUT, "one workgroup owns every output channel of its rows (contiguous NHWC out tile)");
+  const int nt0 = blockIdx.y * (C::NT / 32);  // first 32-channel output tile of this workgroup (grid.y splits COUT when NT < COUT)
   __shared__ __attribute__((aligned(1024))) unsigned char smem[C::LDS];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
@@ -111,7 +111,7 @@ void conv3x3_kernel(ConvArgs a) {
   const unsigned char* wbase = reinterpret_cast<const unsigned char*>(a.wpack);
   const unsigned lane16 = (unsigned)lane * 16u;
   auto wload = [&](int j, int kidx) {
-    const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane(((j * C::WN + wn) * C::KTOT + kidx) * 1024);
+    const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane(((nt0 + j * C::WN + wn) * C::KTOT + kidx) * 1024);
     return *reinterpret_cast<const uint4*>(wbase + soff + lane16);
   };
   const unsigned char* in = reinterpret_cast<const unsigned char*>(a.in);
@@ -134,7 +134,7 @@ void conv3x3_kernel(ConvArgs a) {
       for (int ks = 0; ks < C::KS; ++ks)
 #pragma unroll
         for (int j = 0; j < C::NW; ++j) {
-          const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane(((j * C::WN + wn) * (C::NCH * C::KS) + ch * C::KS + ks) * 1024);
+          const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane(((nt0 + j * C::WN + wn) * (C::NCH * C::KS) + ch * C::KS + ks) * 1024);
           wsc[ks][j] = *reinterpret_cast<const uint4*>(scb + soff + lane16);
         }
     }
@@ -220,7 +220,7 @@ void conv3x3_kernel(ConvArgs a) {
 #pragma unroll
   for (int j = 0; j < C::NW; ++j) {
     __syncthreads();  // every wave is done with the halo tile (j == 0) / the previous sub-tile has been copied out
-    const int nbase = (j * C::WN + wn) * 32;
+    const int nbase = (nt0 + j * C::WN + wn) * 32;
     // residual form: this thread's shortcut chunks are fetched now and consumed after the out tile is staged
     constexpr int CPR = NC * C::EB / 16;             // 16-B chunks per position
     constexpr int NIT = (C::MT * CPR + NTHREADS - 1) / NTHREADS;   // copy-out iterations per thread
@@ -230,7 +230,7 @@ void conv3x3_kernel(ConvArgs a) {
 #pragma unroll
       for (int q = 0; q < NIT; ++q) {
         const int idx = tid + q * NTHREADS, m = idx / CPR, cc = idx % CPR;
-        sreg[q] = (idx < mvalid * CPR) ? *reinterpret_cast<const uint4*>(scut + ((gpos0 + m) * C::COUT + j * NC) * C::EB + cc * 16)
+        sreg[q] = (idx < mvalid * CPR) ? *reinterpret_cast<const uint4*>(scut + ((gpos0 + m) * C::COUT + nt0 * 32 + j * NC) * C::EB + cc * 16)
                                        : make_uint4(0, 0, 0, 0);
       }
     }
@@ -285,7 +285,7 @@ void conv3x3_kernel(ConvArgs a) {
     if (j == 0) stamp(5);
     if (se_part && tid < NC) {
       // edge sums for the next conv's zero padding: a tap shifted by (dh, dw) misses one border row and/or column
-      const int c = tid, cg = j * NC + c, rows_valid = mvalid / C::WOUT, hl = hout_b - 1;
+      const int c = tid, cg = nt0 * 32 + j * NC + c, rows_valid = mvalid / C::WOUT, hl = hout_b - 1;
       float c0 = 0.f, cl = 0.f;
       for (int hr = 0; hr < rows_valid; ++hr) {
         c0 += lds_elem(hr * C::WOUT, c);
@@ -332,7 +332,7 @@ void conv3x3_kernel(ConvArgs a) {
             v = __builtin_bit_cast(uint4, make_float4(relu_nan(vf.x + sf.x), relu_nan(vf.y + sf.y), relu_nan(vf.z + sf.z), relu_nan(vf.w + sf.w)));
           }
         }
-        *reinterpret_cast<uint4*>(out + ((gpos0 + m) * C::COUT + j * NC) * C::EB + cc * 16) = v;
+        *reinterpret_cast<uint4*>(out + ((gpos0 + m) * C::COUT + nt0 * 32 + j * NC) * C::EB + cc * 16) = v;
       }
     }
   }
@@ -345,7 +345,7 @@ void conv3x3_kernel(ConvArgs a) {
 template <class C>
 static int launch_cfg(const ConvArgs& a, hipStream_t st) {
   const int tiles = cdiv(a.Hout, C::TH);
-  dim3 grid((unsigned)(a.B * tiles));
+  dim3 grid((unsigned)(a.B * tiles), C::COUT / C::NT);
   if constexpr (C::TAPS == 9 && C::NW == 1) {
     if (a.sc_wpack) {
       hipLaunchKernelGGL((conv3x3_kernel<C, true>), grid, dim3(C::WM * C::WN * 64), 0, st, a);
@@ -369,9 +369,9 @@ using B_L2   = ConvCfg<bf16_t,  64,  64, 1, 40,  8, 2, 2, 5, 1, 64, 9>;
 using B_L3A  = ConvCfg<bf16_t,  64, 128, 2, 40,  8, 1, 4, 5, 1, 64, 9>;
 using B_L3S  = ConvCfg<bf16_t,  64, 128, 2, 40,  8, 1, 4, 5, 1, 64, 1>;
 using B_L3   = ConvCfg<bf16_t, 128, 128, 1, 20,  8, 1, 4, 5, 1, 128, 9>;
-using B_L4A  = ConvCfg<bf16_t, 128, 256, 2, 20, 16, 1, 4, 5, 2, 64, 9>;
-using B_L4S  = ConvCfg<bf16_t, 128, 256, 2, 20, 16, 1, 4, 5, 2, 64, 1>;
-using B_L4   = ConvCfg<bf16_t, 256, 256, 1, 10, 16, 1, 4, 5, 2, 128, 9>;
+using B_L4A  = ConvCfg<bf16_t, 128, 256, 2, 20, 16, 1, 4, 5, 1, 64, 9>;    // NT = 128: grid.y = 2, 80 accumulator registers
+using B_L4S  = ConvCfg<bf16_t, 128, 256, 2, 20, 16, 1, 4, 5, 1, 64, 1>;
+using B_L4   = ConvCfg<bf16_t, 256, 256, 1, 10, 16, 1, 4, 5, 1, 128, 9>;   // NT = 128: two workgroups per CU
 
 using F_L1   = ConvCfg<float,  32,  32, 1, 80,  8, 4, 1, 5, 1, 32, 9>;
 using F_L1S  = ConvCfg<float,  32,  32, 1, 80,  8, 4, 1, 5, 1, 32, 1>;
