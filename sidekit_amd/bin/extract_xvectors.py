@@ -1,0 +1,135 @@
+"""wav.scp -> x-vector ark/scp: the driver of ``sidekit/bin/extract_xvectors.py`` on the MI355X path.
+
+Same arguments and files (``--model --wav-scp --out-scp [--out-spk-scp --spk2utt-file] --device
+--sample-rate``).  Differences, all on the caller's side of ``Xtractor.forward``: utterances are
+length-sorted into padded batches (``--batch-size``, each row is still processed as if run alone),
+the bf16 trunk can be selected (``--dtype bf16``), ``--vad`` is refused (the reference fetches Silero
+VAD with ``torch.hub`` at run time, ``extract_xvectors.py:102`` -- no network here).  PCM wavs are
+decoded with ``scipy.io.wavfile`` (``soundfile`` is not installed); ``cmd |`` entries are run through
+the shell exactly as the reference does (``:57-70``).
+"""
+import argparse
+import io
+import os
+import subprocess
+
+import numpy
+import scipy.io.wavfile
+import torch
+
+from ..kaldi_io import ArkScpWriter, read_scp
+from ..nnet.xvector import Xtractor
+
+
+def read_wav_scp(wav_scp):
+    utt2wav = {}
+    with open(wav_scp) as f:
+        for line in f:
+            parts = line.strip().split()
+            if parts:
+                utt2wav[parts[0]] = parts[1:]
+    return utt2wav
+
+
+def prepare(wav):
+    """One wav.scp entry -> (float32 1-D tensor in [-1, 1), sample rate)."""
+    wav = ' '.join(wav)
+    if wav.strip().endswith("|"):
+        try:
+            out = subprocess.run(wav.strip()[:-1], shell=True, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout
+            sr, sample = scipy.io.wavfile.read(io.BytesIO(out))
+        except Exception as e:
+            raise IOError("Error processing wav file: {}\n{}".format(wav, e))
+    else:
+        sr, sample = scipy.io.wavfile.read(wav)
+    if sample.ndim > 1:
+        raise IOError(f"{wav}: expected a mono file, got shape {sample.shape}")
+    if sample.dtype == numpy.int16:
+        sample = sample.astype(numpy.float32) / 32768.0
+    elif sample.dtype == numpy.int32:
+        sample = sample.astype(numpy.float32) / 2147483648.0
+    elif sample.dtype == numpy.uint8:
+        sample = (sample.astype(numpy.float32) - 128.0) / 128.0
+    return torch.from_numpy(numpy.ascontiguousarray(sample, dtype=numpy.float32)), sr
+
+
+def load_model(model_path, device):
+    """``extract_xvectors.py:74-89``: checkpoint dict -> Xtractor on ``device`` in eval mode."""
+    device = torch.device(device)
+    checkpoint = torch.load(model_path, map_location="cpu", weights_only=False)
+    archi = checkpoint["model_archi"]
+    emb = archi["embedding_size"] if "embedding_size" in archi else 256
+    xtractor = Xtractor(checkpoint["speaker_number"], model_archi=archi["model_type"], loss=archi["loss"]["type"], embedding_size=emb)
+    xtractor.load_state_dict(checkpoint["model_state_dict"], strict=True)
+    return xtractor.to(device).eval(), archi
+
+
+@torch.no_grad()
+def main(xtractor, wav_scp, out_file, device, sample_rate=16000, out_file_spk="", spk2utt_file="", batch_size=64, dtype="fp32"):
+    utt2wav = read_wav_scp(wav_scp)
+    xtractor.compute_dtype = dtype
+    waves = {}
+    for key, wav in utt2wav.items():
+        signal, sr = prepare(wav)
+        if sr != sample_rate:
+            raise ValueError(f"{key}: sample rate {sr} != {sample_rate} (resampling is out of scope; resample in the wav.scp pipe)")
+        waves[key] = signal
+    # length-sorted batches: bounded padding, every row still computed over its own length
+    order = sorted(waves, key=lambda k: waves[k].numel())
+    vecs = {}
+    for i in range(0, len(order), batch_size):
+        keys = order[i:i + batch_size]
+        lens = [waves[k].numel() for k in keys]
+        batch = torch.zeros(len(keys), max(lens))
+        for r, k in enumerate(keys):
+            batch[r, :lens[r]] = waves[k]
+        out = xtractor(batch.to(xtractor.device, non_blocking=True), is_eval=True, lengths=lens)
+        emb = (out[1] if isinstance(out, tuple) else out).cpu().numpy()
+        for r, k in enumerate(keys):
+            vecs[k] = emb[r:r + 1]          # (1, E) float matrix, what the reference writes (:147)
+    out_ark = os.path.realpath(os.path.join(os.path.dirname(out_file), os.path.splitext(os.path.basename(out_file))[0]))
+    with ArkScpWriter(f"{out_ark}.ark", os.path.realpath(out_file)) as writer:
+        for key in utt2wav:                  # wav.scp order, as the reference
+            writer(key, vecs[key])
+    if out_file_spk:                         # speaker means, L2-normalised (:153-173)
+        spk2utt = {}
+        with open(spk2utt_file) as f:
+            for line in f:
+                parts = line.strip().split()
+                spk2utt[parts[0]] = parts[1:]
+        utt2embd = dict(read_scp(out_file))
+        out_ark_spk = os.path.realpath(os.path.join(os.path.dirname(out_file_spk), os.path.splitext(os.path.basename(out_file_spk))[0]))
+        with ArkScpWriter(f"{out_ark_spk}.ark", os.path.realpath(out_file_spk)) as writer:
+            for spk, utts in spk2utt.items():
+                mean = numpy.mean([utt2embd[u] for u in utts], axis=0)
+                mean /= numpy.linalg.norm(mean, ord=2)
+                writer(spk, mean)
+
+
+def cli(argv=None):
+    parser = argparse.ArgumentParser(description="Extract the x-vectors given a sidekit model (MI355X path)")
+    parser.add_argument("--model", type=str, required=True, help="SideKit model checkpoint")
+    parser.add_argument("--sample-rate", type=int, default=16000, help="Must match SideKit SR model")
+    parser.add_argument("--vad", action='store_true', help="not available: the reference downloads Silero VAD at run time")
+    parser.add_argument("--wav-scp", type=str, required=True)
+    parser.add_argument("--out-scp", type=str, required=True)
+    parser.add_argument("--out-spk-scp", type=str, default="")
+    parser.add_argument("--spk2utt-file", type=str, default="")
+    parser.add_argument("--device", default="cuda", type=str)
+    parser.add_argument("--batch-size", type=int, default=64)
+    parser.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"])
+    args = parser.parse_args(argv)
+    assert os.path.isfile(args.model), "NO SUCH FILE: %s" % args.model
+    assert os.path.isfile(args.wav_scp), "NO SUCH FILE: %s" % args.wav_scp
+    assert os.path.isdir(os.path.dirname(args.out_scp)), "NO SUCH DIRECTORY: %s" % args.out_scp
+    if args.vad:
+        raise NotImplementedError("--vad needs torch.hub.load('snakers4/silero-vad') (remote fetch): out of scope")
+    if args.out_spk_scp:
+        assert os.path.isdir(os.path.dirname(args.out_spk_scp)), "NO SUCH DIRECTORY: %s" % args.out_spk_scp
+        assert os.path.isfile(args.spk2utt_file), "NO SUCH FILE: %s" % args.spk2utt_file
+    xtractor, _ = load_model(args.model, args.device.strip().lower())
+    main(xtractor, args.wav_scp, args.out_scp, args.device, args.sample_rate, args.out_spk_scp, args.spk2utt_file, args.batch_size, args.dtype)
+
+
+if __name__ == '__main__':
+    cli()
