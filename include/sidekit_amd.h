@@ -133,6 +133,14 @@ int sc_plda_fast(const double* d_E, int32_t Ne, const double* d_T, int32_t Nt, i
 int sc_cosine_trials(const float* d_E, const float* d_T, int32_t D, const int32_t* d_enr_idx, const int32_t* d_tst_idx,
                      int64_t n_trials, double* d_out, void* stream);
 
+/* Adaptive symmetric score normalisation, sidekit.score_normalization.asnorm (sidekit/score_normalization.py:120-140).
+ * sc_topk_stats: per row of a (n_rows x n_cols) float32 score matrix, mean and unbiased std of its k largest values
+ * (the reference's `topk(200, dim=1)` + mean/std).  sc_snorm_apply: S[i][j] <- 0.5 ((S - mean_e[i]) / std_e[i] +
+ * (S - mean_t[j]) / std_t[j]) in place. */
+int sc_topk_stats(const float* d_scores, int32_t n_rows, int32_t n_cols, int32_t k, float* d_mean, float* d_std, void* stream);
+int sc_snorm_apply(float* d_S, int32_t Ne, int32_t Nt, const float* d_mean_e, const float* d_std_e, const float* d_mean_t,
+                   const float* d_std_t, void* stream);
+
 /* ---- EER support (host code, no GPU needed) --------------------------------------------------- */
 
 /* sidekit.bosaris.detplot.pavx (sidekit/bosaris/detplot.py:289-351): isotonic (non-decreasing) fit of y.

@@ -4,7 +4,7 @@ TEST INFRASTRUCTURE (see ``oracle/__init__.py``).
 
 Restates the arithmetic of ``sidekit/iv_scoring.py:98-109`` (cosine), ``:428-475`` (fast PLDA),
 ``:303-366`` (full PLDA), ``sidekit/statserver.py:797-817`` (norm / centre) and
-``sidekit/bosaris/detplot.py:289-436`` (pavx, rocch2eer, rocch).  The trial bookkeeping
+``sidekit/bosaris/detplot.py:289-436`` (pavx, rocch2eer, rocch), ``sidekit/score_normalization.py:120-140`` (asnorm).  The trial bookkeeping
 (``Ndx.filter``, ``align_*``) is not restated here: it is pinned directly by the fixtures in
 ``tests/golden/scoring.npz`` made with the imported reference.
 """
@@ -96,6 +96,19 @@ def full_plda_scores(enroll, test, mu, F, G, Sigma, p_known=0.0, scaling_factor=
     s += constant - (S1 + S2[:, numpy.newaxis])
     s *= scaling_factor
     return _open_set(s, p_known) if p_known != 0 else s
+
+
+def asnorm(enrol_xv, cohort_xv, topk=200):
+    """score_normalization.py:120-140 (torch, float32)."""
+    import torch
+    enrol_xv = torch.as_tensor(enrol_xv, dtype=torch.float32)
+    cohort_xv = torch.nn.functional.normalize(torch.as_tensor(cohort_xv, dtype=torch.float32), dim=1)
+    enrol_test_scores = torch.einsum('ij,kj', enrol_xv, enrol_xv).numpy()
+    calib_scores = torch.einsum('ij,kj', enrol_xv, cohort_xv)
+    topk_cohort = calib_scores.topk(topk, dim=1).values
+    calib_mean = topk_cohort.mean(dim=1).numpy()
+    calib_std = topk_cohort.std(dim=1).numpy()
+    return 0.5 * ((enrol_test_scores.T - calib_mean) / calib_std).T + 0.5 * (enrol_test_scores - calib_mean) / calib_std
 
 
 def pavx(y):

@@ -48,6 +48,8 @@ SIGNATURES = {
     "sc_cosine": (ctypes.c_int, [_P, _I32, _P, _I32, _I32, _P, _P]),
     "sc_plda_fast": (ctypes.c_int, [_P, _I32, _P, _I32, _I32, _P, _P, _F64, _F64, _P, _P]),
     "sc_cosine_trials": (ctypes.c_int, [_P, _P, _I32, _P, _P, _I64, _P, _P]),
+    "sc_topk_stats": (ctypes.c_int, [_P, _I32, _I32, _I32, _P, _P, _P]),
+    "sc_snorm_apply": (ctypes.c_int, [_P, _I32, _I32, _P, _P, _P, _P, _P]),
     "sk_bench_conv": (ctypes.c_int, [_I32, _I32, _I32, _I32, _I32, _I32, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(_F64)]),
     "sk_pavx": (ctypes.c_int, [_P, _I64, _P, _P, _P, ctypes.POINTER(_I64)]),
     "sk_rocch_vertices": (ctypes.c_int, [_P, _I64, _I64, _I64, _P, _I64, _P, _P]),

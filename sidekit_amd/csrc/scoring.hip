@@ -88,6 +88,84 @@ __global__ void cosine_trials_kernel(const float* __restrict__ E, const float* _
   if (lane == 0) out[k] = uv / (sqrt(uu) * sqrt(vv));  // 1 - scipy.spatial.distance.cosine
 }
 
+// ---- adaptive s-norm support (sidekit/score_normalization.py:120-140) -----------------------------------------
+// Mean and unbiased std of the k largest values of every row: an exact radix select on the order-preserving
+// integer image of the floats (four 8-bit passes narrow the k-th largest key), then one pass of sums.  Ties at the
+// threshold contribute exactly the copies torch.topk would keep, so the statistics equal those of any valid top-k.
+__device__ inline unsigned fkey(float f) {
+  const unsigned u = __builtin_bit_cast(unsigned, f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);   // larger float <=> larger key
+}
+
+__global__ __launch_bounds__(256) void topk_stats_kernel(const float* __restrict__ x, int ncols, int k, float* __restrict__ mean,
+                                                         float* __restrict__ stdv) {
+  __shared__ unsigned hist[256];
+  __shared__ unsigned s_prefix, s_remaining;
+  __shared__ double red[2 * 256];
+  const float* row = x + (size_t)blockIdx.x * ncols;
+  const int tid = threadIdx.x;
+  unsigned prefix = 0, mask = 0;
+  unsigned remaining = (unsigned)k;   // how many of the still-undecided keys belong to the top-k
+  for (int shift = 24; shift >= 0; shift -= 8) {
+    hist[tid] = 0;
+    __syncthreads();
+    for (int i = tid; i < ncols; i += 256) {
+      const unsigned key = fkey(row[i]);
+      if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      unsigned acc = 0;
+      int b = 255;
+      for (; b > 0; --b) {
+        if (acc + hist[b] >= remaining) break;
+        acc += hist[b];
+      }
+      s_prefix = prefix | ((unsigned)b << shift);
+      s_remaining = remaining - acc;
+    }
+    __syncthreads();
+    prefix = s_prefix;
+    remaining = s_remaining;
+    mask |= 255u << shift;
+    __syncthreads();
+  }
+  // prefix == key of the k-th largest value; `remaining` copies of it are inside the top-k
+  double s1 = 0.0, s2 = 0.0;
+  float tval = 0.f;
+  for (int i = tid; i < ncols; i += 256) {
+    const float v = row[i];
+    const unsigned key = fkey(v);
+    if (key > prefix) { s1 += (double)v; s2 += (double)v * (double)v; }
+    if (key == prefix) tval = v;
+  }
+  red[tid] = s1; red[256 + tid] = s2;
+  __shared__ float s_tval;
+  if (fkey(tval) == prefix) s_tval = tval;   // every writer holds the same value
+  __syncthreads();
+  if (tid == 0) {
+    double a = 0.0, b = 0.0;
+    for (int q = 0; q < 256; ++q) { a += red[q]; b += red[256 + q]; }
+    const double tv = (double)s_tval;
+    a += tv * (double)remaining;
+    b += tv * tv * (double)remaining;
+    const double m = a / (double)k;
+    mean[blockIdx.x] = (float)m;
+    const double var = (b - (double)k * m * m) / (double)(k - 1);
+    stdv[blockIdx.x] = (float)sqrt(var > 0.0 ? var : 0.0);
+  }
+}
+
+// S[i][j] <- 0.5 * ((S[i][j] - me[i]) / se[i] + (S[i][j] - mt[j]) / st[j])
+__global__ void snorm_apply_kernel(float* __restrict__ S, int ne, int nt, const float* __restrict__ me, const float* __restrict__ se,
+                                   const float* __restrict__ mt, const float* __restrict__ st) {
+  const long i = blockIdx.x * 256L + threadIdx.x;
+  if (i >= (long)ne * nt) return;
+  const int r = (int)(i / nt), c = (int)(i % nt);
+  const float v = S[i];
+  S[i] = 0.5f * ((v - me[r]) / se[r]) + 0.5f * ((v - mt[c]) / st[c]);
+}
+
 static int dgemm(bool b_kn, const double* A, const double* B, double* C, int M, int N, int K, const double* rt, const double* ct,
                  double cst, double alpha, hipStream_t s) {
   const dim3 grid(cdiv(N, DT), cdiv(M, DT));
@@ -132,6 +210,22 @@ int sc_plda_fast(const double* d_E, int32_t Ne, const double* d_T, int32_t Nt, i
   } while (0);
   (void)hipFreeAsync(tmp, st); (void)hipFreeAsync(qe, st); (void)hipFreeAsync(qt, st);
   return rc;
+}
+
+int sc_topk_stats(const float* d_scores, int32_t n_rows, int32_t n_cols, int32_t k, float* d_mean, float* d_std, void* stream) {
+  SK_CHECK(d_scores && d_mean && d_std && n_rows > 0 && k > 1 && k <= n_cols, SK_EARG, "sc_topk_stats: need 1 < k <= n_cols (k=%d, n_cols=%d)", k, n_cols);
+  hipLaunchKernelGGL(topk_stats_kernel, dim3(n_rows), dim3(256), 0, (hipStream_t)stream, d_scores, n_cols, k, d_mean, d_std);
+  SK_HIP(hipGetLastError());
+  return SK_OK;
+}
+
+int sc_snorm_apply(float* d_S, int32_t Ne, int32_t Nt, const float* d_mean_e, const float* d_std_e, const float* d_mean_t,
+                   const float* d_std_t, void* stream) {
+  SK_CHECK(d_S && d_mean_e && d_std_e && d_mean_t && d_std_t && Ne > 0 && Nt > 0, SK_EARG, "sc_snorm_apply: bad arguments");
+  hipLaunchKernelGGL(snorm_apply_kernel, dim3((unsigned)(((long)Ne * Nt + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_S, Ne, Nt,
+                     d_mean_e, d_std_e, d_mean_t, d_std_t);
+  SK_HIP(hipGetLastError());
+  return SK_OK;
 }
 
 int sc_cosine_trials(const float* d_E, const float* d_T, int32_t D, const int32_t* d_enr_idx, const int32_t* d_tst_idx, int64_t n_trials,

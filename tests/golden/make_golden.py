@@ -13,7 +13,7 @@ The torchaudio stand-in's MelSpectrogram / MFCC compute with oracle/frontend.py 
 restatement of torchaudio 0.8.2), so every *network* fixture is cut at the features seam, where no
 stand-in arithmetic is involved; wav-level fixtures are labelled `unpinned_frontend`.
 
-Usage:  PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+Usage:  PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py [halfresnet34] [tdnn] [scoring] [asnorm]
 """
 import importlib
 import os
@@ -327,12 +327,31 @@ def scoring_fixtures(mods, out):
     print("scoring.npz", sorted(fx))
 
 
+def asnorm_fixtures(mods, out):
+    from oracle import scoring as osc
+    sn = importlib.import_module("sidekit.score_normalization")
+    g = torch.Generator().manual_seed(31)
+    spk = torch.randn(12, 256, generator=g)
+    enrol = torch.nn.functional.normalize(spk[torch.randint(0, 12, (64,), generator=g)] + 0.7 * torch.randn(64, 256, generator=g), dim=1)
+    cohort = 3.0 * torch.randn(300, 256, generator=g)          # un-normalised on purpose
+    s = sn.asnorm(enrol, cohort, None)
+    assert numpy.allclose(osc.asnorm(enrol, cohort), s, atol=1e-6)
+    numpy.savez_compressed(os.path.join(out, "asnorm.npz"), seed=31, enrol=enrol.numpy(), cohort=cohort.numpy(), snorm=s.astype(numpy.float32))
+    print("asnorm.npz", s.shape, s.dtype)
+
+
 def main():
     mods = import_reference()
     torch.set_num_threads(8)
-    halfresnet_fixtures(mods, HERE)
-    tdnn_fixtures(mods, HERE)
-    scoring_fixtures(mods, HERE)
+    only = sys.argv[1:] or ["halfresnet34", "tdnn", "scoring", "asnorm"]
+    if "halfresnet34" in only:
+        halfresnet_fixtures(mods, HERE)
+    if "tdnn" in only:
+        tdnn_fixtures(mods, HERE)
+    if "scoring" in only:
+        scoring_fixtures(mods, HERE)
+    if "asnorm" in only:
+        asnorm_fixtures(mods, HERE)
 
 
 if __name__ == "__main__":

@@ -121,3 +121,20 @@ def test_listed_trials_cosine(gpu):
     e64, t64 = E.astype(numpy.float64), T.astype(numpy.float64)
     ref = (e64[ei] * t64[ti]).sum(1) / (numpy.linalg.norm(e64[ei], axis=1) * numpy.linalg.norm(t64[ti], axis=1))
     numpy.testing.assert_allclose(out.cpu().numpy(), ref, rtol=1e-12, atol=1e-14)
+
+
+def test_asnorm_golden_and_large(gpu, golden_dir):
+    """Adaptive s-norm (score_normalization.py:120-140): reference fixture, then a cohort with heavy ties at scale."""
+    from sidekit_amd.score_normalization import asnorm
+    fx = numpy.load(os.path.join(golden_dir, "asnorm.npz"))
+    got = asnorm(torch.from_numpy(fx["enrol"]), torch.from_numpy(fx["cohort"]), None)
+    assert got.dtype == numpy.float32 and got.shape == (64, 64)
+    numpy.testing.assert_allclose(got, fx["snorm"], rtol=2e-5, atol=2e-5)
+    rs = numpy.random.RandomState(9)
+    e = rs.randn(700, 256).astype(numpy.float32)
+    e /= numpy.linalg.norm(e, axis=1, keepdims=True)
+    cohort = numpy.round(rs.randn(5000, 256), 1).astype(numpy.float32)       # coarse values -> tied cohort scores
+    cohort[100:140] = cohort[100]                                            # 40 identical cohort speakers
+    numpy.testing.assert_allclose(asnorm(e, cohort), osc.asnorm(e, cohort), rtol=5e-5, atol=5e-5)
+    with pytest.raises(ValueError):
+        asnorm(e[:4], cohort[:100], topk=200)                                # k > cohort size

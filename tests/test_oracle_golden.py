@@ -140,3 +140,8 @@ def test_frontend_building_blocks():
     # N4: CMVN makes the features invariant to input gain
     w = 0.1 * torch.randn(1, 3000)
     numpy.testing.assert_allclose(ofe.melspec_frontend(w).numpy(), ofe.melspec_frontend(0.5 * w).numpy(), atol=2e-3)
+
+
+def test_asnorm_oracle_matches_reference(golden_dir):
+    fx = numpy.load(os.path.join(golden_dir, "asnorm.npz"))
+    numpy.testing.assert_allclose(osc.asnorm(fx["enrol"], fx["cohort"]), fx["snorm"], atol=1e-6)
