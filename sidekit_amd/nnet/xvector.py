@@ -147,7 +147,7 @@ class Xtractor:
         emb = torch.empty((B, self.embedding_size), dtype=torch.float32, device=x.device)
         logits = torch.empty((B, int(self.speaker_number)), dtype=torch.float32, device=x.device) if self.loss == "aam" else None
         lens = self._lengths(lengths, B, L)
-        _lib.check(lib.xt_forward(h, x.data_ptr(), x.stride(0), _ptr(lens), B, L, emb.data_ptr(),
+        _lib.check(lib.xt_forward(h, x.data_ptr(), x.stride(0) if B > 1 else L, _ptr(lens), B, L, emb.data_ptr(),
                                   logits.data_ptr() if logits is not None else None, self._stream(x)))
         return (logits, emb) if self.loss == "aam" else emb
 
@@ -177,7 +177,7 @@ class Xtractor:
         T = 1 + L // self.preprocessor.hop_length
         out = torch.empty((B, 80, T), dtype=torch.float32, device=x.device)
         lens = self._lengths(lengths, B, L)
-        _lib.check(_lib.lib().xt_features(h, x.data_ptr(), x.stride(0), _ptr(lens), B, L, out.data_ptr(), self._stream(x)))
+        _lib.check(_lib.lib().xt_features(h, x.data_ptr(), x.stride(0) if B > 1 else L, _ptr(lens), B, L, out.data_ptr(), self._stream(x)))
         return out
 
     def debug_taps(self, names, dtype=None):
@@ -309,3 +309,114 @@ class Xtractor:
             self._drop_handles()
         except Exception:
             pass
+
+
+# ---- library-level extraction driver --------------------------------------------------------------
+def _load_segment(data_root_name, seg_id, file_extension, start_cs, stop_cs, sample_rate, min_duration):
+    """One IdMap row -> (float32 waveform tensor, start sample, stop sample): the ``__getitem__`` of the reference's
+    ``IdMapSet`` (``sidekit/nnet/xsets.py:420-466``; start / stop are centiseconds, ``None`` = whole file; a segment
+    shorter than ``min_duration`` seconds is widened around its middle).  PCM wav files are read with ``scipy.io.wavfile``
+    (torchaudio is not installed)."""
+    import scipy.io.wavfile
+    sr, x = scipy.io.wavfile.read(f"{data_root_name}/{seg_id}.{file_extension}")
+    if sr != sample_rate:
+        raise ValueError(f"{seg_id}: sample rate {sr} != {sample_rate} (resampling is out of scope)")
+    if x.ndim > 1:
+        x = x[:, 0]
+    if x.dtype == numpy.int16:
+        x = x.astype(numpy.float32) / 32768.0
+    elif x.dtype == numpy.int32:
+        x = x.astype(numpy.float32) / 2147483648.0
+    x = numpy.ascontiguousarray(x, dtype=numpy.float32)
+    start = 0 if start_cs is None else int(start_cs * 0.01 * sample_rate)
+    if stop_cs is None:
+        duration = int(x.shape[0] - start)          # the reference keeps the whole file in this branch
+    else:
+        duration = int(stop_cs * 0.01 * sample_rate) - start
+        if duration <= min_duration * sample_rate:
+            middle = start + duration // 2
+            start = int(max(0, int(middle - (min_duration * sample_rate / 2))))
+            duration = int(min_duration * sample_rate)
+        x = x[start:start + duration]
+    return torch.from_numpy(x), start, start + duration
+
+
+def extract_embeddings(idmap_name, model_filename, data_root_name, device, batch_size=1, file_extension="wav", transform_pipeline={},
+                       sliding_window=False, win_duration=3., win_shift=1.5, num_thread=1, sample_rate=16000, mixed_precision=False,
+                       norm_embeddings=True):
+    """``sidekit.nnet.xvector.extract_embeddings`` (``sidekit/nnet/xvector.py:1796-1916``): x-vectors of every segment
+    of an IdMap, returned as a ``StatServer`` (``stat1`` = x-vectors, ``stat0`` = ones, ids as unicode arrays).
+
+    Same arguments.  Differences on the driver side only: ``batch_size`` utterances go through one padded forward
+    (every row computed over its own length), sliding windows of a file form one batch, ``mixed_precision`` selects the
+    bf16 trunk (the reference's fp16 autocast), augmentation pipelines are training-time and refused; for sliding windows
+    ``stop`` is ``start + window length`` in samples (the reference stores ``start + 1`` there, ``:1901-1911``)."""
+    from ..bosaris import IdMap
+    from ..statserver import StatServer
+    if transform_pipeline:
+        raise NotImplementedError("augmentation pipelines are training-time (out of scope)")
+    if isinstance(model_filename, str):
+        checkpoint = torch.load(model_filename, map_location="cpu", weights_only=False)
+        model_opts = checkpoint["model_archi"]
+        model = Xtractor(checkpoint["speaker_number"], model_archi=model_opts["model_type"], loss=model_opts["loss"]["type"],
+                         embedding_size=256)
+        model.load_state_dict(checkpoint["model_state_dict"])
+    else:
+        model = model_filename
+    idmap = idmap_name if isinstance(idmap_name, IdMap) else IdMap(idmap_name)
+    model.eval()
+    model.to(device)
+    prev_dtype = model.compute_dtype
+    if mixed_precision and model.model_archi == "halfresnet34":
+        model.compute_dtype = "bf16"
+    win_len, win_hop = int(win_duration * sample_rate), int(win_shift * sample_rate)
+    embed, modelset, segset, starts, stops = [], [], [], [], []
+
+    def run(batch, lens):
+        out = model(batch.to(model.device), is_eval=True, norm_embedding=norm_embeddings, lengths=lens)
+        return (out[1] if isinstance(out, tuple) else out).detach().cpu()
+
+    try:
+        with torch.no_grad():
+            if sliding_window:
+                for i in range(idmap.leftids.shape[0]):
+                    speech, start, _ = _load_segment(data_root_name, idmap.rightids[i], file_extension, idmap.start[i], idmap.stop[i],
+                                                     sample_rate, win_duration)
+                    windows = speech.unfold(0, win_len, win_hop)                      # (n_windows, win_len)
+                    for j in range(0, windows.shape[0], max(1, 100)):
+                        embed.append(run(windows[j:j + 100].contiguous(), None))
+                    n = windows.shape[0]
+                    modelset.extend([idmap.leftids[i]] * n)
+                    segset.extend([idmap.rightids[i]] * n)
+                    w0 = numpy.arange(n) * win_hop + start
+                    starts.extend(w0.tolist())
+                    stops.extend((w0 + win_len).tolist())
+            else:
+                items = [_load_segment(data_root_name, idmap.rightids[i], file_extension, idmap.start[i], idmap.stop[i], sample_rate,
+                                       win_duration) for i in range(idmap.leftids.shape[0])]
+                order = sorted(range(len(items)), key=lambda i: items[i][0].numel())
+                vec = [None] * len(items)
+                for j in range(0, len(order), max(1, batch_size)):
+                    idx = order[j:j + max(1, batch_size)]
+                    lens = [items[i][0].numel() for i in idx]
+                    batch = torch.zeros(len(idx), max(lens))
+                    for r, i in enumerate(idx):
+                        batch[r, :lens[r]] = items[i][0]
+                    out = run(batch, lens)
+                    for r, i in enumerate(idx):
+                        vec[i] = out[r:r + 1]
+                embed = vec
+                modelset = list(idmap.leftids)
+                segset = list(idmap.rightids)
+                starts = [it[1] for it in items]
+                stops = [it[1] + it[0].numel() for it in items]
+    finally:
+        model.compute_dtype = prev_dtype
+    embeddings = StatServer()
+    embeddings.stat1 = numpy.concatenate([e.numpy() for e in embed])
+    embeddings.modelset = numpy.array(modelset).astype('>U')
+    embeddings.segset = numpy.array(segset).astype('>U')
+    embeddings.start = numpy.array(starts).squeeze()
+    embeddings.stop = numpy.array(stops).squeeze()
+    embeddings.stat0 = numpy.ones((embeddings.modelset.shape[0], 1))
+    return embeddings
