@@ -99,7 +99,7 @@ struct xt_handle {
 
   // workspace
   int max_batch = 0; int64_t max_samples = 0;
-  DevBuf ws_S, ws_feat, ws_act[4], ws_se, ws_col, ws_edge, ws_splitk, ws_gate, ws_ctx, ws_rb, ws_h, ws_e, ws_pooled, ws_pre, ws_emb, ws_int, ws_ragged;
+  DevBuf ws_S, ws_feat, ws_act[4], ws_se, ws_col, ws_edge, ws_splitk, ws_gate, ws_ctx, ws_rb, ws_h, ws_e, ws_pooled, ws_pre, ws_int;
   // pinned staging ring for per-utterance integers
   static constexpr int RING = 4;
   int* ring_host[RING] = {nullptr, nullptr, nullptr, nullptr};
@@ -747,7 +747,7 @@ int xt_destroy(xt_handle* h) {
   if (!h) return SK_OK;
   for (void* p : h->dev_allocs) (void)hipFree(p);
   DevBuf* bufs[] = {&h->ws_S, &h->ws_feat, &h->ws_act[0], &h->ws_act[1], &h->ws_act[2], &h->ws_act[3], &h->ws_se, &h->ws_col, &h->ws_edge, &h->ws_splitk, &h->ws_gate,
-                    &h->ws_ctx, &h->ws_rb, &h->ws_h, &h->ws_e, &h->ws_pooled, &h->ws_pre, &h->ws_emb, &h->ws_int, &h->ws_ragged};
+                    &h->ws_ctx, &h->ws_rb, &h->ws_h, &h->ws_e, &h->ws_pooled, &h->ws_pre, &h->ws_int};
   for (DevBuf* b : bufs) b->release();
   for (auto& kv : h->taps) kv.second.buf.release();
   for (auto& r : h->prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
@@ -821,7 +821,6 @@ int xt_reserve(xt_handle* h, int32_t max_batch, int64_t max_samples) {
   const size_t E = (size_t)h->cfg.emb_dim;
   SK_TRY(h->ws_pre.ensure(B * E * 4));
   SK_TRY(h->ws_splitk.ensure((size_t)32 * (B < 512 ? B : 512) * 256 * 4));  // split-K partials of the skinny GEMMs (N <= 256)
-  SK_TRY(h->ws_emb.ensure(B * E * 4));
   if (h->cfg.arch == XT_ARCH_HALFRESNET34) {
     const size_t EB = h->cfg.dtype == XT_BF16 ? 2 : 4;
     for (int i = 0; i < 4; ++i) SK_TRY(h->ws_act[i].ensure(R * 80 * 32 * EB));

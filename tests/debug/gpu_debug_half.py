@@ -1,6 +1,6 @@
 """Stage-wise parity of the HalfResNet34 path against the oracle (debug helper, GPU box)."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy, torch
 from sidekit_amd.nnet import Xtractor
 from sidekit_amd.nnet.weights import seeded_state_dict

@@ -1,6 +1,6 @@
 """Front-end + TDNN + ragged-batch parity against the oracle (debug helper, GPU box)."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy, torch
 from sidekit_amd.nnet import Xtractor
 from oracle import xvector as oxv, frontend as ofe

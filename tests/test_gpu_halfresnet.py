@@ -164,3 +164,18 @@ def test_error_behaviour(model):
     nan = torch.zeros(16000).cuda()                                   # a silent utterance: constant features -> CMVN 0/eps, finite
     _, e = model(nan, is_eval=True)
     assert bool(torch.isfinite(e).all())
+
+
+def test_row_tile_boundaries(model):
+    """Frame counts around the conv row tiles (8 / 16 rows) and the stride-2 halvings: every length alone vs the oracle."""
+    sd = model.state_dict()
+    frames = [9, 15, 16, 17, 31, 33, 63, 64, 65, 127, 129]
+    lens = [(t - 1) * 160 + 7 for t in frames]          # T = 1 + L // 160
+    lens = [max(n, 513) for n in lens]                  # reflect padding needs > 512 samples
+    torch.manual_seed(12)
+    wav = 0.1 * torch.randn(len(lens), max(lens))
+    with torch.no_grad():
+        _, ref = oxv.forward_ragged([wav[i, :n] for i, n in enumerate(lens)], sd)
+    _, emb = model(wav.cuda(), is_eval=True, lengths=lens)
+    for i, n in enumerate(lens):
+        assert rel(emb[i], ref[i]) < TOL, (i, n, 1 + n // 160)
