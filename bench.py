@@ -147,7 +147,8 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with torch.distributed.run)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or "RANK" in os.environ   # under torch.distributed.run the RCCL path is exercised even at N = 1
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
 
@@ -157,11 +158,11 @@ def main():
     B, L = args.batch, int(args.seconds * 16000)
     g = torch.Generator(device=dev).manual_seed(rank)
     wav = 0.1 * torch.randn(B, L, device=dev, generator=g)
-    gathered = torch.empty(world * B, model.embedding_size, device=dev) if world > 1 else None
+    gathered = torch.empty(world * B, model.embedding_size, device=dev) if use_dist else None
 
     def step():
         _, emb = model(wav, is_eval=True)
-        if world > 1:
+        if use_dist:
             dist.all_gather_into_tensor(gathered, emb)
         return emb
 
@@ -171,21 +172,22 @@ def main():
         model.set_profile(True)
         model.get_profile(reset=True)
     torch.cuda.synchronize(dev)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         emb = step()
     torch.cuda.synchronize(dev)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
     assert bool(torch.isfinite(emb).all()), "non-finite x-vectors"
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        assert torch.equal(gathered[rank * B:(rank + 1) * B], emb), "all-gather returned a different block for this rank"
     dt = t.item()
 
     if rank == 0:
@@ -197,7 +199,7 @@ def main():
             "config": {"workload": f"{'HalfResNet34' if args.arch == 'halfresnet34' else 'TDNN x-vector'} Xtractor.forward(is_eval=True), "
                                    f"{dtype} trunk, batch={B} per GPU, synthetic {args.seconds:g} s @ 16 kHz (BASELINE.json configs[1])",
                        "batch_per_gpu": B, "samples_per_utt": L, "frames_per_utt": T,
-                       "parallelism": f"utterance-sharded x{world}" + (" + RCCL all-gather of x-vectors" if world > 1 else "")},
+                       "parallelism": f"utterance-sharded x{world}" + (" + RCCL all-gather of x-vectors" if use_dist else "")},
         }
         if not args.no_profile:
             prof = model.get_profile(reset=True)
@@ -208,7 +210,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline and args.arch == "halfresnet34":
             out["cpu_baseline"] = cpu_baseline(args.seconds)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
