@@ -150,6 +150,69 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   }
 }
 
+// ---- bf16 form: same 64x64 tile, k-tile of 64 bf16, v_mfma_f32_32x32x16_bf16 ------------------------------------
+// A rows are bf16 already (trunk output) or f32 converted on the way to LDS; W comes pre-converted.  LDS rows are
+// 128 B + 16 B pad (9 slots: conflict-free ds_read_b128).
+constexpr int BKH = 64, LDH = BKH * 2 + 16;
+
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) unsigned char As[BM * LDH];
+  __shared__ __attribute__((aligned(16))) unsigned char Ws[BN * LDH];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  // staging: 64 rows x 8 chunks of 8 bf16 -> 512 chunks per operand, 2 per thread
+  const int srow = tid >> 3, sk8 = (tid & 7) * 8;
+  uint4 ra[2], rw[2];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int row = srow + q * 32, m = m0 + row, n = n0 + row, k = k0 + sk8;
+      uint4 va = make_uint4(0, 0, 0, 0), vw = make_uint4(0, 0, 0, 0);
+      if (m < g.M && k < g.K) {
+        if (g.a_bf16) {
+          va = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(g.A) + (long)m * g.lda + k);
+        } else {
+          const float* p = reinterpret_cast<const float*>(g.A) + (long)m * g.lda + k;
+          const float4 x = *reinterpret_cast<const float4*>(p), y = *reinterpret_cast<const float4*>(p + 4);
+          va = make_uint4(pack_bf16x2(x.x, x.y), pack_bf16x2(x.z, x.w), pack_bf16x2(y.x, y.y), pack_bf16x2(y.z, y.w));
+        }
+      }
+      if (n < g.N && k < g.K) vw = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(g.W_bf16) + (long)n * g.ldw + k);
+      ra[q] = va; rw[q] = vw;
+    }
+  };
+  f32x16 acc;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+  const int nk = (g.K + BKH - 1) / BKH;
+  fetch(0);
+  for (int kt = 0; kt < nk; ++kt) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      *reinterpret_cast<uint4*>(As + (srow + q * 32) * LDH + sk8 * 2) = ra[q];
+      *reinterpret_cast<uint4*>(Ws + (srow + q * 32) * LDH + sk8 * 2) = rw[q];
+    }
+    __syncthreads();
+    if (kt + 1 < nk) fetch((kt + 1) * BKH);
+#pragma unroll
+    for (int kk = 0; kk < BKH; kk += 16) {
+      const uint4 a = *reinterpret_cast<const uint4*>(As + (wm * 32 + r) * LDH + (kk + 8 * h) * 2);
+      const uint4 b = *reinterpret_cast<const uint4*>(Ws + (wn * 32 + r) * LDH + (kk + 8 * h) * 2);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  const int n = n0 + wn * 32 + r;
+  if (n >= g.N) return;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int m = m0 + wm * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+    if (m < g.M) g.C[(long)m * g.ldc + n] = gemm_epilogue(g, acc[q], m, n);
+  }
+}
+
 __global__ __launch_bounds__(256) void gemm_splitk_epilogue_kernel(GemmArgs g) {
   const long i = blockIdx.x * 256L + threadIdx.x;
   if (i >= (long)g.M * g.N) return;
@@ -169,6 +232,11 @@ int launch_gemm(const GemmArgs& g_in, hipStream_t s) {
   SK_CHECK(g.M > 0 && g.N > 0 && g.K > 0, SK_EARG, "gemm: empty problem %dx%dx%d", g.M, g.N, g.K);
   SK_CHECK(g.K % 4 == 0 && g.ldw % 4 == 0, SK_EARG, "gemm: K=%d / ldw=%ld must be multiples of 4", g.K, g.ldw);
   SK_CHECK(g.a_mode != A_PLAIN || (g.lda % 4 == 0 && g.kc % 4 == 0), SK_EARG, "gemm: lda/kc alignment");
+  if (g.W_bf16 && g.a_mode == A_PLAIN && g.kc == 0 && g.K % 8 == 0 && g.lda % 8 == 0 && g.ldw % 8 == 0 && g.ksplit == 1) {
+    hipLaunchKernelGGL(gemm_bf16_kernel, dim3(cdiv(g.M, BM), cdiv(g.N, BN)), dim3(256), 0, s, g);
+    SK_HIP(hipGetLastError());
+    return SK_OK;
+  }
   dim3 grid(cdiv(g.M, BM), cdiv(g.N, BN), g.ksplit);
   switch (g.a_mode) {
     case A_PLAIN: hipLaunchKernelGGL(gemm_kernel<LoadPlain>, grid, dim3(256), 0, s, g); break;

@@ -102,6 +102,8 @@ struct GemmArgs {
   const float* shift;   // [N]
   float alpha;          // final multiplier
   // split-K for skinny problems (M <= 512, K large: 16 workgroups would otherwise walk thousands of k-steps serially):
+  const void* W_bf16;   // optional bf16 copy of W ([N][K], ldw elements): with a_mode == A_PLAIN and K % 8 == 0 the product runs on the
+                        // bf16 MFMA (operands rounded to bf16, f32 accumulate) -- used by the bf16 compute path only
   float* splitk_ws;     // [ksplit][M][N] partial sums, or null (no split)
   int ksplit;           // set by launch_gemm
 };

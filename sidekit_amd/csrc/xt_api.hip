@@ -91,6 +91,7 @@ struct xt_handle {
   std::vector<Block> blocks;
   float *att_w1x = nullptr, *att_w1c = nullptr, *att_b1 = nullptr, *att_bn_scale = nullptr, *att_bn_shift = nullptr;
   float *att_w2 = nullptr, *att_b2 = nullptr;
+  void *att_w1x_bf16 = nullptr, *att_w2_bf16 = nullptr;   // bf16 copies for the bf16 compute path
   float *emb_w = nullptr, *emb_scale = nullptr, *emb_shift = nullptr, *emb_bias = nullptr;
   float* head_wn = nullptr;  // row-normalised ArcMargin weight
   // tdnn
@@ -359,6 +360,14 @@ static int finalize_half(xt_handle* h) {
     b2p[dp] = b2[d];
   }
   SK_TRY(upload_f(h, w2p, &h->att_w2));
+  if (h->cfg.dtype == XT_BF16) {
+    std::vector<uint16_t> hb(w1x.size());
+    for (size_t i = 0; i < w1x.size(); ++i) hb[i] = f32_to_bf16(w1x[i]);
+    SK_TRY(upload(h, hb.data(), hb.size() * 2, &h->att_w1x_bf16));
+    hb.resize(w2p.size());
+    for (size_t i = 0; i < w2p.size(); ++i) hb[i] = f32_to_bf16(w2p[i]);
+    SK_TRY(upload(h, hb.data(), hb.size() * 2, &h->att_w2_bf16));
+  }
   SK_TRY(upload_f(h, b2p, &h->att_b2));
   const int E = h->cfg.emb_dim;
   const auto& lw = T(h, "before_speaker_embedding.lin_be.weight");  // [E][5120] = [mu(d) | rh(d)]
@@ -616,11 +625,11 @@ static int half_from_feats(xt_handle* h, const float* feats, long sb, long sf, l
   GemmArgs g1 = gemm_args();  // attention.0 on x + ReLU + BatchNorm1d + tanh
   g1.A = X; g1.a_bf16 = xbf; g1.lda = D; g1.a_rows = R; g1.W = h->att_w1x; g1.ldw = D; g1.C = (float*)h->ws_h.p; g1.ldc = 128;
   g1.M = R; g1.N = 128; g1.K = D; g1.rowbias = (const float*)h->ws_rb.p; g1.rows_per_group = H4;
-  g1.act = ACT_RELU_BN_TANH; g1.scale = h->att_bn_scale; g1.shift = h->att_bn_shift;
+  g1.act = ACT_RELU_BN_TANH; g1.scale = h->att_bn_scale; g1.shift = h->att_bn_shift; g1.W_bf16 = h->att_w1x_bf16;
   SK_TRY(launch_gemm(g1, st));
   GemmArgs g2 = gemm_args();  // attention.4
   g2.A = h->ws_h.p; g2.lda = 128; g2.a_rows = R; g2.W = h->att_w2; g2.ldw = 128; g2.C = (float*)h->ws_e.p; g2.ldc = D;
-  g2.M = R; g2.N = D; g2.K = 128; g2.bias = h->att_b2;
+  g2.M = R; g2.N = D; g2.K = 128; g2.bias = h->att_b2; g2.W_bf16 = h->att_w2_bf16;
   SK_TRY(launch_gemm(g2, st));
   SK_TRY(launch_att_stats(X, xbf, (const float*)h->ws_e.p, D, D, rs, (float*)h->ws_pooled.p, B, st));
   SK_TRY(tap(h, "pooled", h->ws_pooled.p, (size_t)B * 2 * D * 4, st));
