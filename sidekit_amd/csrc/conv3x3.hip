@@ -32,7 +32,7 @@ template <> __device__ inline void mma_step<float>(f32x16& acc, const uint4& w, 
   acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, w.w), __builtin_bit_cast(float, x.w), acc, 0, 0, 0);
 }
 
-template <typename T_, int CIN_, int COUT_, int S_, int WIN_, int TH_, int WM_, int WN_, int MW_, int NW_, int CK_, int TAPS_>
+template <typename T_, int CIN_, int COUT_, int S_, int WIN_, int TH_, int WM_, int WN_, int MW_, int NW_, int CK_, int TAPS_, int OCC_ = 0, int PD_ = 0, bool SWZ_ = false>
 struct ConvCfg {
   using T = T_;
   static constexpr int EB = elem<T_>::bytes;
@@ -44,15 +44,32 @@ struct ConvCfg {
   static constexpr int RIN = (TH - 1) * S + 3;   // staged input rows
   static constexpr int WP = WIN + 2;             // staged input columns (zero column each side)
   static constexpr int CB = CK * EB;             // channel bytes staged per position
-  static constexpr int PSTRIDE = CB + 16;        // +16 B: ds_read_b128 of 32 neighbouring positions is conflict-free
+  // Two LDS images of the halo tile:
+  //  padded   (SWZ = false): [zero col][WIN positions][zero col], CB + 16 B per position (the +16 makes ds_read_b128 of 32
+  //           neighbouring positions conflict-free), rows on 1-KiB piece boundaries.  Pad slots and zero columns are DMA
+  //           lanes that read the zero page: 70 pieces for a layer1 tile of 51 KB.
+  //  swizzled (SWZ = true): CB bytes per position, no pad slots; the 16-B chunk c of column p sits at slot c ^ f(p)
+  //           (f below), which is as conflict-free as the padding and costs nothing to stage because a DMA lane may fetch any
+  //           global address; ONE zero position between rows (and before row 0) is both neighbours' zero column and is
+  //           written once by ds_write.  A row is WIN * CB bytes = whole pieces: 50 pieces for the same layer1 tile.
+  static constexpr bool SWZ = SWZ_;
+  static constexpr int PSTRIDE = SWZ ? CB : CB + 16;
   static constexpr int SPP = PSTRIDE / 16;                // 16-B slots per staged position
-  static constexpr int PPR = (WP * SPP + 63) / 64;        // 1-KiB LDS-DMA pieces per staged row
-  static constexpr int RS = PPR * 1024;                   // LDS row stride: rows start on a piece boundary, so a piece's
-                                                          // (row, column) decode is one scalar division + one lane-side /SPP
-  static constexpr int LDS = RIN * RS;
+  static constexpr int PPR = ((SWZ ? WIN : WP) * SPP + 63) / 64;   // 1-KiB LDS-DMA pieces per staged row
+  static constexpr int RS = SWZ ? (WIN + 1) * CB : PPR * 1024;     // LDS row stride
+  static constexpr int ROW0 = SWZ ? CB : 0;               // offset of row 0 (swizzled: after the leading zero position)
+  static constexpr int LDS = SWZ ? ((ROW0 + (RIN - 1) * RS + PPR * 1024 + 1023) / 1024 * 1024) : RIN * RS;
+  static constexpr int SWF = SPP < 16 ? SPP : 16;         // swizzle period in slots
+  static constexpr int SWSH = SPP == 4 ? 2 : (SPP == 8 ? 1 : 0);   // f(p) = (p >> SWSH) & (SWF - 1): 16 consecutive columns hit 16 distinct bank groups
+  static_assert(!SWZ || (SPP == 4 || SPP == 8 || SPP == 16 || SPP == 32), "swizzled image: 64..512 B per position");
   static constexpr int KS = CB / 32;             // MFMA k-steps (32 B of k) per tap per chunk
   static constexpr int NCH = CIN / CK;           // channel chunks
   static constexpr int KTOT = NCH * TAPS * KS;   // k-steps per output-channel tile
+  // waves per SIMD the kernel is compiled for (caps the register budget at 512 / OCC): by default two workgroups per
+  // CU whenever two halo tiles fit the LDS and the accumulators are small enough
+  static constexpr int OCC = OCC_ ? OCC_ : ((MW * NW <= 5 && 160 * 1024 / LDS * WM * WN >= 8) ? 2 : 1);
+  static constexpr int NK = TAPS * KS;           // k-steps per channel chunk
+  static constexpr int PD = PD_ ? PD_ : ((NK * NW <= 24) ? NK : (NW == 1 ? 8 : 4));   // weight prefetch depth in k-steps
   static_assert(MT == WM * MW * 32, "positions must tile into 32-row MFMA tiles");
   static_assert(COUT % NT == 0 && CIN % CK == 0 && CB % 32 == 0, "channel tiling");
   static_assert(LDS <= 160 * 1024, "LDS budget");
@@ -60,12 +77,16 @@ struct ConvCfg {
 
 // second launch-bound = waves per SIMD: two workgroups per CU whenever two halo tiles fit the LDS, which caps the
 // kernel at 256 registers (VGPR + AGPR) per lane
-template <class C, bool SC>
-__global__ __launch_bounds__(C::WM * C::WN * 64, (!SC && C::MW * C::NW <= 5 && 160 * 1024 / C::LDS * C::WM * C::WN >= 8) ? 2 : 1)
+// FORM selects the epilogue at compile time (the statistics form carries no shortcut registers, the residual form no
+// plane sums): 0 plain, 1 statistics (conv1 of a block), 2 residual (conv2 of a block)
+enum { FORM_PLAIN = 0, FORM_STATS = 1, FORM_RESID = 2 };
+template <int F> struct FormTag { static constexpr int value = F; };
+
+template <class C, bool SC, int FORM>
+__global__ __launch_bounds__(C::WM * C::WN * 64, SC ? 1 : C::OCC)
 void conv3x3_kernel(ConvArgs a) {
   using T = typename C::T;
   constexpr int NWAVES = C::WM * C::WN, NTHREADS = NWAVES * 64;
-  static_assert(NWAVES == 2 || NWAVES == 4, "two or four waves per workgroup");
   const int nt0 = blockIdx.y * (C::NT / 32);  // first 32-channel output tile of this workgroup (grid.y splits COUT when NT < COUT)
   __shared__ __attribute__((aligned(1024))) unsigned char smem[C::LDS];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -86,12 +107,23 @@ void conv3x3_kernel(ConvArgs a) {
   };
   stamp(0);
 
-  int base[C::MW];
+  // per-lane LDS byte offset of (M-tile i, horizontal tap dw) at k-step 0; the swizzled image folds the column's
+  // swizzle into it, and a later k-step ks is then `offset ^ (ks << 5)` instead of `offset + ks * 32`
+  int base[C::MW][C::SWZ ? 3 : 1];
 #pragma unroll
   for (int i = 0; i < C::MW; ++i) {
     const int m = (wm * C::MW + i) * 32 + r;
     const int ho = m / C::WOUT, wo = m % C::WOUT;
-    base[i] = (ho * C::S) * C::RS + (wo * C::S) * C::PSTRIDE + h * 16;
+    if constexpr (C::SWZ) {
+#pragma unroll
+      for (int dw = 0; dw < 3; ++dw) {
+        const int col = wo * C::S + dw - 1;   // -1 / WIN: the zero position before / after the row
+        const int f = (col >> C::SWSH) & (C::SWF - 1);
+        base[i][dw] = C::ROW0 + (ho * C::S) * C::RS + col * C::CB + ((h ^ f) << 4);
+      }
+    } else {
+      base[i][0] = (ho * C::S) * C::RS + (wo * C::S) * C::PSTRIDE + h * 16;
+    }
   }
   f32x16 acc[C::MW][C::NW];
   f32x16 acc_sc[SC ? C::MW : 1][SC ? C::NW : 1];  // fused 1x1 shortcut: centre tap only
@@ -119,14 +151,17 @@ void conv3x3_kernel(ConvArgs a) {
 
   // Weight fragments stream L2 -> VGPR through a small software ring: PD k-steps ahead of their use (all of a
   // chunk's fragments when they fit), so the ~700-cycle L2 latency is paid once per chunk, under the staging DMA.
-  constexpr int NK = C::TAPS * C::KS;                                   // k-steps per channel chunk
-  constexpr int PD = (NK * C::NW <= 24) ? NK : (C::NW == 1 ? 8 : 4);    // prefetch depth in k-steps
+  constexpr int NK = C::NK, PD = C::PD;
+  // packed-weight index (tap * KS + ks) of the kk-th k-step of a chunk (see the k-step order below)
+  auto kord = [](int kk) {
+    return (C::SWZ && C::TAPS == 9) ? ((kk % 3) * 3 + kk / (3 * C::KS)) * C::KS + (kk / 3) % C::KS : kk;
+  };
   for (int ch = 0; ch < C::NCH; ++ch) {
     uint4 wq[PD][C::NW];
 #pragma unroll
     for (int d = 0; d < PD; ++d)
 #pragma unroll
-      for (int j = 0; j < C::NW; ++j) wq[d][j] = wload(j, ch * NK + d);
+      for (int j = 0; j < C::NW; ++j) wq[d][j] = wload(j, ch * NK + kord(d));
     uint4 wsc[SC ? C::KS : 1][SC ? C::NW : 1];
     if constexpr (SC) {
       const unsigned char* scb = reinterpret_cast<const unsigned char*>(a.sc_wpack);
@@ -144,25 +179,45 @@ void conv3x3_kernel(ConvArgs a) {
     // every piece in flight at once).  A lane whose slot is a pad slot or a zero-padding position reads the zero page
     // (measured: masking those lanes off and zero-filling with ds_write instead is 20 % slower).
     constexpr int CPP = C::CB / 16, NPIECE = C::RIN * C::PPR;
+    if constexpr (C::SWZ) {
+      if (ch == 0) {  // the zero positions between rows: never touched by the DMA, valid for every channel chunk
+        for (int s = tid; s < (C::RIN + 1) * C::SPP; s += NTHREADS)
+          *reinterpret_cast<uint4*>(smem + (s / C::SPP) * C::RS + (s % C::SPP) * 16) = make_uint4(0, 0, 0, 0);
+      }
+    }
     for (int it = (a.dbg & 4) ? NPIECE : wave; it < NPIECE; it += NWAVES) {
       const int row = it / C::PPR, q = it % C::PPR;          // wave-uniform
       const int hi = hi0 + row;
       const bool rowok = hi >= 0 && hi < hin_b;
       const unsigned char* rowbase = in + ((((size_t)b * a.Hin + hi) * C::WIN) * C::CIN + ch * C::CK) * C::EB;
       const int slot = q * 64 + lane;
-      const int col = slot / C::SPP, cc = slot - col * C::SPP;
       const unsigned char* src = reinterpret_cast<const unsigned char*>(a.zeros);
-      if (rowok && cc < CPP && col >= 1 && col <= C::WIN) src = rowbase + (col - 1) * (C::CIN * C::EB) + cc * 16;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(smem + it * 1024), 16, 0, 0);
+      if constexpr (C::SWZ) {
+        const int col = slot / C::SPP, cs = slot % C::SPP;
+        const int cc = cs ^ ((col >> C::SWSH) & (C::SWF - 1));
+        if (rowok) src = rowbase + col * (C::CIN * C::EB) + cc * 16;
+        if ((C::WIN * C::SPP) % 64 == 0 || slot < C::WIN * C::SPP)  // a partial last piece must not run into the next row
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                           (__attribute__((address_space(3))) void*)(smem + C::ROW0 + row * C::RS + q * 1024), 16, 0, 0);
+      } else {
+        const int col = slot / C::SPP, cc = slot - col * C::SPP;
+        if (rowok && cc < CPP && col >= 1 && col <= C::WIN) src = rowbase + (col - 1) * (C::CIN * C::EB) + cc * 16;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(smem + it * 1024), 16, 0, 0);
+      }
     }
     stamp(1);
     __syncthreads();
     stamp(2);
+    // k-step order inside a chunk: (tap, ks) for the padded image; the swizzled image walks (dw, ks, dh) so that one
+    // swizzled address serves three consecutive steps (the row offset is an instruction immediate) and then dies
+    auto step_tap = [](int kk) { return (C::SWZ && C::TAPS == 9) ? (kk % 3) * 3 + kk / (3 * C::KS) : kk / C::KS; };
+    auto step_ks = [](int kk) { return (C::SWZ && C::TAPS == 9) ? (kk / 3) % C::KS : kk % C::KS; };
     auto xaddr = [&](int i, int kk) {
-      const int t = kk / C::KS, ks = kk % C::KS;
+      const int t = step_tap(kk), ks = step_ks(kk);
       const int tap = (C::TAPS == 9) ? t : 4;
-      return smem + base[i] + (tap / 3) * C::RS + (tap % 3) * C::PSTRIDE + ks * 32;
+      if constexpr (C::SWZ) return smem + (base[i][tap % 3] ^ (ks << 5)) + (tap / 3) * C::RS;
+      else return smem + base[i][0] + (tap / 3) * C::RS + (tap % 3) * C::PSTRIDE + ks * 32;
     };
     uint4 xc[C::MW], xn[C::MW];
 #pragma unroll
@@ -179,7 +234,7 @@ void conv3x3_kernel(ConvArgs a) {
       for (int j = 0; j < C::NW; ++j) wf[j] = wq[kk % PD][j];
       if (kk + PD < NK) {
 #pragma unroll
-        for (int j = 0; j < C::NW; ++j) wq[kk % PD][j] = wload(j, ch * NK + kk + PD);
+        for (int j = 0; j < C::NW; ++j) wq[kk % PD][j] = wload(j, ch * NK + kord(kk + PD));
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -187,11 +242,11 @@ void conv3x3_kernel(ConvArgs a) {
 #pragma unroll
         for (int j = 0; j < C::NW; ++j) mma_step<T>(acc[i][j], wf[j], xc[i]);
       if constexpr (SC) {
-        if (kk / C::KS == 4) {  // centre tap: the strided 1x1 shortcut sees exactly these activation fragments
+        if (step_tap(kk) == 4) {  // centre tap: the strided 1x1 shortcut sees exactly these activation fragments
 #pragma unroll
           for (int i = 0; i < C::MW; ++i)
 #pragma unroll
-            for (int j = 0; j < C::NW; ++j) mma_step<T>(acc_sc[i][j], wsc[kk % C::KS][j], xc[i]);
+            for (int j = 0; j < C::NW; ++j) mma_step<T>(acc_sc[i][j], wsc[step_ks(kk)][j], xc[i]);
         }
       }
 #pragma unroll
@@ -216,7 +271,10 @@ void conv3x3_kernel(ConvArgs a) {
   };
   stamp(3);
   // one output stream: (accumulators, BN scale/shift, destination, epilogue form)
-  auto emit = [&](auto& accv, const float* scale, const float* shift, unsigned char* out, const float* gate, float* se_part, bool relu) {
+  auto emit = [&](auto form, auto& accv, const float* scale, const float* shift, unsigned char* out, bool relu) {
+  constexpr bool STATS = decltype(form)::value == FORM_STATS, RESID = decltype(form)::value == FORM_RESID;
+  const float* gate = RESID ? a.gate : nullptr;
+  float* se_part = STATS ? a.se_part : nullptr;
 #pragma unroll
   for (int j = 0; j < C::NW; ++j) {
     __syncthreads();  // every wave is done with the halo tile (j == 0) / the previous sub-tile has been copied out
@@ -225,8 +283,8 @@ void conv3x3_kernel(ConvArgs a) {
     constexpr int CPR = NC * C::EB / 16;             // 16-B chunks per position
     constexpr int NIT = (C::MT * CPR + NTHREADS - 1) / NTHREADS;   // copy-out iterations per thread
     const unsigned char* scut = reinterpret_cast<const unsigned char*>(a.shortcut);
-    uint4 sreg[NIT];
-    if (gate) {
+    uint4 sreg[RESID ? NIT : 1];
+    if constexpr (RESID) {
 #pragma unroll
       for (int q = 0; q < NIT; ++q) {
         const int idx = tid + q * NTHREADS, m = idx / CPR, cc = idx % CPR;
@@ -242,7 +300,7 @@ void conv3x3_kernel(ConvArgs a) {
     for (int g = 0; g < 4; ++g) {
       sc[g] = *reinterpret_cast<const f32x4*>(scale + nbase + 8 * g + 4 * h);
       sh[g] = *reinterpret_cast<const f32x4*>(shift + nbase + 8 * g + 4 * h);
-      if (gate) gt[g] = *reinterpret_cast<const f32x4*>(gate + (size_t)b * C::COUT + nbase + 8 * g + 4 * h);
+      if constexpr (RESID) gt[g] = *reinterpret_cast<const f32x4*>(gate + (size_t)b * C::COUT + nbase + 8 * g + 4 * h);
     }
 #pragma unroll
     for (int i = 0; i < C::MW; ++i) {
@@ -255,17 +313,17 @@ void conv3x3_kernel(ConvArgs a) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           float x = accv[i][j][4 * g + q] * sc[g][q] + sh[g][q];
-          if (gate) x *= gt[g][q];
+          if constexpr (RESID) x *= gt[g][q];
           else if (relu) x = relu_nan(x);
           if constexpr (C::EB == 2) x = round_bf16(x);  // what is stored (and what the next conv reads)
           v[q] = x;
-          ssum[4 * g + q] += valid ? x : 0.f;
+          if constexpr (STATS) ssum[4 * g + q] += valid ? x : 0.f;
         }
         if constexpr (C::EB == 2) *reinterpret_cast<uint2*>(lp + 8 * g * 2) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
         else *reinterpret_cast<float4*>(lp + 8 * g * 4) = make_float4(v[0], v[1], v[2], v[3]);
       }
     }
-    if (se_part) {
+    if constexpr (STATS) {
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         float s = ssum[q];
@@ -283,7 +341,7 @@ void conv3x3_kernel(ConvArgs a) {
     if (j == 0) stamp(4);
     __syncthreads();  // out sub-tile complete
     if (j == 0) stamp(5);
-    if (se_part && tid < NC) {
+    if (STATS && tid < NC) {
       // edge sums for the next conv's zero padding: a tap shifted by (dh, dw) misses one border row and/or column
       const int c = tid, cg = nt0 * 32 + j * NC + c, rows_valid = mvalid / C::WOUT, hl = hout_b - 1;
       float c0 = 0.f, cl = 0.f;
@@ -317,7 +375,7 @@ void conv3x3_kernel(ConvArgs a) {
         const int idx = tid + q * NTHREADS, m = idx / CPR, cc = idx % CPR;
         if (idx >= mvalid * CPR) break;
         uint4 v = *reinterpret_cast<const uint4*>(smem + m * OPS + cc * 16);
-        if (gate) {
+        if constexpr (RESID) {
           const uint4 s = sreg[q];
           if constexpr (C::EB == 2) {
             const uint32_t vv[4] = {v.x, v.y, v.z, v.w}, ss[4] = {s.x, s.y, s.z, s.w};
@@ -337,8 +395,8 @@ void conv3x3_kernel(ConvArgs a) {
     }
   }
   };
-  emit(acc, a.scale, a.shift, reinterpret_cast<unsigned char*>(a.out), a.gate, a.se_part, a.relu != 0);
-  if constexpr (SC) emit(acc_sc, a.sc_scale, a.sc_shift, reinterpret_cast<unsigned char*>(a.sc_out), nullptr, nullptr, false);
+  emit(FormTag<FORM>{}, acc, a.scale, a.shift, reinterpret_cast<unsigned char*>(a.out), a.relu != 0);
+  if constexpr (SC) emit(FormTag<FORM_PLAIN>{}, acc_sc, a.sc_scale, a.sc_shift, reinterpret_cast<unsigned char*>(a.sc_out), false);
   stamp(6);
 }
 
@@ -346,26 +404,44 @@ template <class C>
 static int launch_cfg(const ConvArgs& a, hipStream_t st) {
   const int tiles = cdiv(a.Hout, C::TH);
   dim3 grid((unsigned)(a.B * tiles), C::COUT / C::NT);
-  if constexpr (C::TAPS == 9 && C::NW == 1) {
+  const dim3 block(C::WM * C::WN * 64);
+  SK_CHECK(!(a.gate && a.se_part), SK_EARG, "a convolution is either the statistics or the residual form");
+  if constexpr (C::TAPS == 9 && C::NW == 1 && C::S == 2) {
     if (a.sc_wpack) {
-      hipLaunchKernelGGL((conv3x3_kernel<C, true>), grid, dim3(C::WM * C::WN * 64), 0, st, a);
+      SK_CHECK(a.se_part, SK_EARG, "the fused shortcut belongs to the first convolution of a block (statistics form)");
+      hipLaunchKernelGGL((conv3x3_kernel<C, true, FORM_STATS>), grid, block, 0, st, a);
       SK_HIP(hipGetLastError());
       return SK_OK;
     }
   }
   SK_CHECK(!a.sc_wpack, SK_EARG, "this convolution shape has no fused-shortcut form");
-  hipLaunchKernelGGL((conv3x3_kernel<C, false>), grid, dim3(C::WM * C::WN * 64), 0, st, a);
+  if constexpr (C::TAPS == 9) {
+    if (a.se_part) {
+      hipLaunchKernelGGL((conv3x3_kernel<C, false, FORM_STATS>), grid, block, 0, st, a);
+      SK_HIP(hipGetLastError());
+      return SK_OK;
+    }
+    if constexpr (C::S == 1) {
+      if (a.gate) {
+        hipLaunchKernelGGL((conv3x3_kernel<C, false, FORM_RESID>), grid, block, 0, st, a);
+        SK_HIP(hipGetLastError());
+        return SK_OK;
+      }
+    }
+  }
+  SK_CHECK(!a.gate && !a.se_part, SK_EARG, "this convolution shape has no statistics / residual form");
+  hipLaunchKernelGGL((conv3x3_kernel<C, false, FORM_PLAIN>), grid, block, 0, st, a);
   SK_HIP(hipGetLastError());
   return SK_OK;
 }
 
 // ---- the trunk's convolution shapes ---------------------------------------------------------
 //                      T      CIN COUT S WIN TH WM WN MW NW  CK TAPS
-using B_L1   = ConvCfg<bf16_t,  32,  32, 1, 80,  8, 4, 1, 5, 1, 32, 9>;
-using B_L1S  = ConvCfg<bf16_t,  32,  32, 1, 80,  8, 4, 1, 5, 1, 32, 1>;
-using B_L2A  = ConvCfg<bf16_t,  32,  64, 2, 80,  8, 2, 2, 5, 1, 32, 9>;
-using B_L2S  = ConvCfg<bf16_t,  32,  64, 2, 80,  8, 2, 2, 5, 1, 32, 1>;
-using B_L2   = ConvCfg<bf16_t,  64,  64, 1, 40,  8, 2, 2, 5, 1, 64, 9>;
+using B_L1   = ConvCfg<bf16_t,  32,  32, 1, 80,  8, 4, 1, 5, 1, 32, 9, 0, 0, true>;
+using B_L1S  = ConvCfg<bf16_t,  32,  32, 1, 80,  8, 4, 1, 5, 1, 32, 1, 0, 0, true>;
+using B_L2A  = ConvCfg<bf16_t,  32,  64, 2, 80,  8, 2, 2, 5, 1, 32, 9, 0, 0, true>;
+using B_L2S  = ConvCfg<bf16_t,  32,  64, 2, 80,  8, 2, 2, 5, 1, 32, 1, 0, 0, true>;
+using B_L2   = ConvCfg<bf16_t,  64,  64, 1, 40,  8, 2, 2, 5, 1, 64, 9, 0, 0, true>;
 using B_L3A  = ConvCfg<bf16_t,  64, 128, 2, 40,  8, 1, 4, 5, 1, 64, 9>;
 using B_L3S  = ConvCfg<bf16_t,  64, 128, 2, 40,  8, 1, 4, 5, 1, 64, 1>;
 using B_L3   = ConvCfg<bf16_t, 128, 128, 1, 20,  8, 1, 4, 5, 1, 128, 9>;
@@ -373,11 +449,25 @@ using B_L4A  = ConvCfg<bf16_t, 128, 256, 2, 20, 16, 1, 4, 5, 1, 64, 9>;    // NT
 using B_L4S  = ConvCfg<bf16_t, 128, 256, 2, 20, 16, 1, 4, 5, 1, 64, 1>;
 using B_L4   = ConvCfg<bf16_t, 256, 256, 1, 10, 16, 1, 4, 5, 1, 128, 9>;   // NT = 128: two workgroups per CU
 
-using F_L1   = ConvCfg<float,  32,  32, 1, 80,  8, 4, 1, 5, 1, 32, 9>;
-using F_L1S  = ConvCfg<float,  32,  32, 1, 80,  8, 4, 1, 5, 1, 32, 1>;
-using F_L2A  = ConvCfg<float,  32,  64, 2, 80,  8, 2, 2, 5, 1, 16, 9>;
-using F_L2S  = ConvCfg<float,  32,  64, 2, 80,  8, 2, 2, 5, 1, 16, 1>;
-using F_L2   = ConvCfg<float,  64,  64, 1, 40,  8, 2, 2, 5, 1, 64, 9>;
+// tuning candidates (sk_bench_conv shapes 11..): smaller halo tiles, more workgroups per CU
+using B_X0   = ConvCfg<bf16_t,  32,  32, 1, 80,  8, 4, 1, 5, 1, 32, 9>;     // L1 swizzled image, 2 WGs/CU
+using B_X1   = ConvCfg<bf16_t,  32,  64, 2, 80,  8, 2, 2, 5, 1, 32, 9>;     // L1 swizzled, 3 WGs/CU (168 registers)
+using B_X2   = ConvCfg<bf16_t,  64,  64, 1, 40,  8, 2, 2, 5, 1, 64, 9>;     // L2 swizzled
+using B_X3   = ConvCfg<bf16_t,  32,  32, 1, 80,  8, 4, 1, 5, 1, 32, 1>;     // L2 swizzled, 3 WGs/CU
+using B_X4   = ConvCfg<bf16_t, 128, 128, 1, 20,  8, 1, 4, 5, 1, 128, 9, 2, 0, true>;    // L3 swizzled
+using B_X5   = ConvCfg<bf16_t, 256, 256, 1, 10, 16, 1, 4, 5, 1, 128, 9, 2, 0, true>;    // L4 swizzled (partial last piece)
+using F_X4 = ConvCfg<float, 128, 128, 1, 20,  8, 1, 4, 5, 1, 128, 9>;
+using F_X5 = ConvCfg<float, 256, 256, 1, 10, 16, 1, 4, 5, 2, 128, 9>;
+using F_X0 = ConvCfg<float,  32,  32, 1, 80,  8, 4, 1, 5, 1, 32, 9>;
+using F_X1 = ConvCfg<float,  32,  64, 2, 80,  8, 2, 2, 5, 1, 16, 9>;
+using F_X2 = ConvCfg<float,  64,  64, 1, 40,  8, 2, 2, 5, 1, 64, 9>;
+using F_X3 = ConvCfg<float,  32,  32, 1, 80,  8, 4, 1, 5, 1, 32, 1>;
+
+using F_L1   = ConvCfg<float,  32,  32, 1, 80,  8, 4, 1, 5, 1, 32, 9, 0, 0, true>;
+using F_L1S  = ConvCfg<float,  32,  32, 1, 80,  8, 4, 1, 5, 1, 32, 1, 0, 0, true>;
+using F_L2A  = ConvCfg<float,  32,  64, 2, 80,  8, 2, 2, 5, 1, 16, 9, 0, 0, true>;
+using F_L2S  = ConvCfg<float,  32,  64, 2, 80,  8, 2, 2, 5, 1, 16, 1, 0, 0, true>;
+using F_L2   = ConvCfg<float,  64,  64, 1, 40,  8, 2, 2, 5, 1, 64, 9, 0, 0, true>;
 using F_L3A  = ConvCfg<float,  64, 128, 2, 40,  8, 1, 4, 5, 1, 32, 9>;
 using F_L3S  = ConvCfg<float,  64, 128, 2, 40,  8, 1, 4, 5, 1, 32, 1>;
 using F_L3   = ConvCfg<float, 128, 128, 1, 20,  8, 1, 4, 5, 1, 128, 9>;
@@ -393,7 +483,8 @@ static void fill_geom(ConvGeom& g) {
 
 #define SK_CONV_CASES(X) \
   X(CONV_L1, L1) X(CONV_L1S, L1S) X(CONV_L2A, L2A) X(CONV_L2S, L2S) X(CONV_L2, L2) X(CONV_L3A, L3A) \
-  X(CONV_L3S, L3S) X(CONV_L3, L3) X(CONV_L4A, L4A) X(CONV_L4S, L4S) X(CONV_L4, L4)
+  X(CONV_L3S, L3S) X(CONV_L3, L3) X(CONV_L4A, L4A) X(CONV_L4S, L4S) X(CONV_L4, L4) \
+  X(11, X0) X(12, X1) X(13, X2) X(14, X3) X(15, X4) X(16, X5)
 
 int conv_geom(int shape, int dtype, ConvGeom* g) {
   switch (shape) {

@@ -955,7 +955,7 @@ int sk_bench_conv(int32_t shape, int32_t dtype, int32_t B, int32_t T, int32_t it
   void *in = nullptr, *out = nullptr, *w = nullptr, *zeros = nullptr; float *sc = nullptr, *sh = nullptr, *se = nullptr;
   SK_HIP(hipMalloc(&in, in_b)); SK_HIP(hipMalloc(&out, out_b)); SK_HIP(hipMalloc(&w, conv_pack_bytes(g) + 4096));
   SK_HIP(hipMalloc(&zeros, 256)); SK_HIP(hipMalloc((void**)&sc, g.cout * 4)); SK_HIP(hipMalloc((void**)&sh, g.cout * 4));
-  SK_HIP(hipMalloc((void**)&se, (size_t)B * (hout / g.th + 2) * 4 * g.cout * 4));
+  SK_HIP(hipMalloc((void**)&se, (size_t)B * (hout / g.th + 2) * (g.wm > 4 ? g.wm : 4) * g.cout * 4));
   SK_HIP(hipMemset(in, 0x3c, in_b)); SK_HIP(hipMemset(w, 0x3c, conv_pack_bytes(g))); SK_HIP(hipMemset(zeros, 0, 256));
   SK_HIP(hipMemset(sc, 0, g.cout * 4)); SK_HIP(hipMemset(sh, 0, g.cout * 4));
   ConvArgs a;
