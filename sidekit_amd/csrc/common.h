@@ -1,6 +1,7 @@
 // Shared device/host helpers for the sidekit_amd HIP library (gfx950 / CDNA4 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -88,6 +89,22 @@ struct Lens {
   int uniform;        // used when frames == nullptr
   __device__ inline int get(int b) const { return frames ? frames[b] : uniform; }
 };
+
+// Sum over each 32-lane half of the wave on the VALU's DPP path (no LDS crossbar traffic, 5 adds): xor-1 and xor-2 inside
+// quads, half-mirror and mirror inside the 16-lane rows, then row_bcast:15 carries row 0 / row 2's sum into row 1 / row 3.
+// The result is valid in lanes 16..31 (sum of lanes 0..31) and 48..63 (sum of lanes 32..63) only.
+__device__ inline float half_sum_upper_row(float v) {
+  auto dpp = [](float x, auto ctrl, auto row_mask) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, decltype(row_mask)::value, 0xf, false));
+  };
+  using std::integral_constant;
+  v += dpp(v, integral_constant<int, 0xB1>{}, integral_constant<int, 0xf>{});    // quad_perm [1,0,3,2]
+  v += dpp(v, integral_constant<int, 0x4E>{}, integral_constant<int, 0xf>{});    // quad_perm [2,3,0,1]
+  v += dpp(v, integral_constant<int, 0x141>{}, integral_constant<int, 0xf>{});   // row_half_mirror
+  v += dpp(v, integral_constant<int, 0x140>{}, integral_constant<int, 0xf>{});   // row_mirror
+  v += dpp(v, integral_constant<int, 0x142>{}, integral_constant<int, 0xa>{});   // row_bcast:15 into rows 1 and 3 (others add 0)
+  return v;
+}
 
 __device__ inline float wave_sum(float v) {
 #pragma unroll

@@ -325,13 +325,8 @@ void conv3x3_kernel(ConvArgs a) {
     }
     if constexpr (STATS) {
 #pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        float s = ssum[q];
-#pragma unroll
-        for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o);
-        ssum[q] = s;
-      }
-      if (r == 0) {
+      for (int q = 0; q < 16; ++q) ssum[q] = half_sum_upper_row(ssum[q]);
+      if (r == 16) {
         float* sp = se_part + (((size_t)b * tiles + tile) * C::WM + wm) * C::COUT + nbase + 4 * h;
 #pragma unroll
         for (int g = 0; g < 4; ++g)
