@@ -70,6 +70,7 @@ struct ConvCfg {
   static constexpr int OCC = OCC_ ? OCC_ : ((MW * NW <= 5 && 160 * 1024 / LDS * WM * WN >= 8) ? 2 : 1);
   static constexpr int NK = TAPS * KS;           // k-steps per channel chunk
   static constexpr int PD = PD_ ? PD_ : ((NK * NW <= 24) ? NK : (NW == 1 ? 8 : 4));   // weight prefetch depth in k-steps
+  static constexpr bool RESIDENT = TAPS == 9 && NCH == 1 && PD == NK && NT == COUT;   // a wave keeps all its weight fragments in registers
   static_assert(MT == WM * MW * 32, "positions must tile into 32-row MFMA tiles");
   static_assert(COUT % NT == 0 && CIN % CK == 0 && CB % 32 == 0, "channel tiling");
   static_assert(LDS <= 160 * 1024, "LDS budget");
@@ -95,17 +96,15 @@ void conv3x3_kernel(ConvArgs a) {
   const int tiles = (a.Hout + C::TH - 1) / C::TH;
   // XCD-aware order: blocks are dealt round-robin over the 8 XCDs (bid % 8 shares an L2), so give every XCD a
   // contiguous run of (utterance, row-tile) work items -> vertically adjacent tiles share their halo rows in L2
-  const int nblk = gridDim.x, q8 = nblk >> 3, r8 = nblk & 7, xcd = blockIdx.x & 7;
-  const int work = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
-  const int b = work / tiles, tile = work % tiles;
-  const int ho0 = tile * C::TH;
-  const int hin_b = halve(a.lens.get(b), a.halvings_in);
-  const int hout_b = (C::S == 2) ? ((hin_b + 1) >> 1) : hin_b;
-  if (ho0 >= hout_b) return;  // nothing valid in this tile (its SE partial is never read)
+  // The grid is either one workgroup per work item or (weight-resident shapes, see RESIDENT) as many workgroups as the
+  // chip holds at once, each walking every wstride-th item of its XCD's run -- neighbouring workgroups of an XCD are
+  // then always on neighbouring tiles.
+  const int nwork = a.B * tiles, q8 = nwork >> 3, r8 = nwork & 7, xcd = blockIdx.x & 7;
+  const int wfirst = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8, wcount = q8 + (xcd < r8 ? 1 : 0);
+  const int wstride = (int)(gridDim.x >> 3) + (xcd < (int)(gridDim.x & 7) ? 1 : 0);
   auto stamp = [&](int k) {  // diagnostic build path only (a.stamps == nullptr in the product)
     if (a.stamps && tid == 0) a.stamps[(size_t)blockIdx.x * 8 + k] = __builtin_amdgcn_s_memtime();
   };
-  stamp(0);
 
   // per-lane LDS byte offset of (M-tile i, horizontal tap dw) at k-step 0; the swizzled image folds the column's
   // swizzle into it, and a later k-step ks is then `offset ^ (ks << 5)` instead of `offset + ks * 32`
@@ -125,6 +124,62 @@ void conv3x3_kernel(ConvArgs a) {
       base[i][0] = (ho * C::S) * C::RS + (wo * C::S) * C::PSTRIDE + h * 16;
     }
   }
+  // Output-channel tile of (wave column wn, repeat j) = j*WN + wn: for a fixed j the workgroup's WN*32 channels are
+  // contiguous, so the staged out tile leaves as contiguous NHWC rows.  Fragment address = wave-uniform (SGPR)
+  // offset + 32-bit lane offset, so no per-fragment 64-bit VGPR address is kept alive.
+  const unsigned char* wbase = reinterpret_cast<const unsigned char*>(a.wpack);
+  const unsigned lane16 = (unsigned)lane * 16u;
+  auto wload = [&](int j, int kidx) {
+    const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane(((nt0 + j * C::WN + wn) * C::KTOT + kidx) * 1024);
+    return *reinterpret_cast<const uint4*>(wbase + soff + lane16);
+  };
+  const unsigned char* in = reinterpret_cast<const unsigned char*>(a.in);
+
+  // Weight fragments stream L2 -> VGPR through a small software ring: PD k-steps ahead of their use, so the ~700-cycle
+  // L2 latency is paid once per chunk, under the staging DMA.  When ALL of a wave's fragments fit the ring (C = 32
+  // inputs: 72 registers) they are loaded once per workgroup and the workgroup is persistent: per tile that removes
+  // 72 KB of L2->VGPR traffic from a vector-memory path that also has to carry the tile's 50 KB of DMA and its stores.
+  constexpr int NK = C::NK, PD = C::PD;
+  constexpr bool RESIDENT = C::RESIDENT;
+  // packed-weight index (tap * KS + ks) of the kk-th k-step of a chunk (see the k-step order below)
+  auto kord = [](int kk) {
+    return (C::SWZ && C::TAPS == 9) ? ((kk % 3) * 3 + kk / (3 * C::KS)) * C::KS + (kk / 3) % C::KS : kk;
+  };
+  uint4 wq[PD][C::NW];
+  uint4 wsc[SC ? C::KS : 1][SC ? C::NW : 1];
+  auto load_weights = [&](int ch) {
+#pragma unroll
+    for (int d = 0; d < PD; ++d)
+#pragma unroll
+      for (int j = 0; j < C::NW; ++j) wq[d][j] = wload(j, ch * NK + kord(d));
+    if constexpr (SC) {
+      const unsigned char* scb = reinterpret_cast<const unsigned char*>(a.sc_wpack);
+#pragma unroll
+      for (int ks = 0; ks < C::KS; ++ks)
+#pragma unroll
+        for (int j = 0; j < C::NW; ++j) {
+          const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane(((nt0 + j * C::WN + wn) * (C::NCH * C::KS) + ch * C::KS + ks) * 1024);
+          wsc[ks][j] = *reinterpret_cast<const uint4*>(scb + soff + lane16);
+        }
+    }
+  };
+  if constexpr (RESIDENT) load_weights(0);
+
+  const int tid0 = tid;
+  auto do_item = [&](int work, bool first_item) -> bool {  // returns whether the tile touched the LDS
+  // persistent form: hide the thread index from loop-invariant code motion -- hoisting every tile-independent DMA and
+  // copy-out offset out of the tile loop costs ~40 registers (spills); recomputing them per tile is a few VALU ops
+  int tid = tid0;
+  if constexpr (RESIDENT) asm volatile("" : "+v"(tid));
+  const int lane = tid & 63, r = lane & 31, h = lane >> 5;
+  const int b = work / tiles, tile = work % tiles;
+  const int ho0 = tile * C::TH;
+  const int hin_b = __builtin_amdgcn_readfirstlane(halve(a.lens.get(b), a.halvings_in));  // wave-uniform: keep the row bounds in SGPRs
+  const int hout_b = (C::S == 2) ? ((hin_b + 1) >> 1) : hin_b;
+  if (ho0 >= hout_b) return false;  // nothing valid in this tile (its SE partial is never read)
+  if (!first_item) __syncthreads();  // the previous tile's copy-out has left the LDS
+  stamp(0);
+  const int hi0 = ho0 * C::S - 1;
   f32x16 acc[C::MW][C::NW];
   f32x16 acc_sc[SC ? C::MW : 1][SC ? C::NW : 1];  // fused 1x1 shortcut: centre tap only
 #pragma unroll
@@ -137,42 +192,8 @@ void conv3x3_kernel(ConvArgs a) {
         if constexpr (SC) acc_sc[i][j][q] = 0.f;
       }
 
-  // Output-channel tile of (wave column wn, repeat j) = j*WN + wn: for a fixed j the workgroup's WN*32 channels are
-  // contiguous, so the staged out tile leaves as contiguous NHWC rows.  Fragment address = wave-uniform (SGPR)
-  // offset + 32-bit lane offset, so no per-fragment 64-bit VGPR address is kept alive.
-  const unsigned char* wbase = reinterpret_cast<const unsigned char*>(a.wpack);
-  const unsigned lane16 = (unsigned)lane * 16u;
-  auto wload = [&](int j, int kidx) {
-    const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane(((nt0 + j * C::WN + wn) * C::KTOT + kidx) * 1024);
-    return *reinterpret_cast<const uint4*>(wbase + soff + lane16);
-  };
-  const unsigned char* in = reinterpret_cast<const unsigned char*>(a.in);
-  const int hi0 = ho0 * C::S - 1;
-
-  // Weight fragments stream L2 -> VGPR through a small software ring: PD k-steps ahead of their use (all of a
-  // chunk's fragments when they fit), so the ~700-cycle L2 latency is paid once per chunk, under the staging DMA.
-  constexpr int NK = C::NK, PD = C::PD;
-  // packed-weight index (tap * KS + ks) of the kk-th k-step of a chunk (see the k-step order below)
-  auto kord = [](int kk) {
-    return (C::SWZ && C::TAPS == 9) ? ((kk % 3) * 3 + kk / (3 * C::KS)) * C::KS + (kk / 3) % C::KS : kk;
-  };
   for (int ch = 0; ch < C::NCH; ++ch) {
-    uint4 wq[PD][C::NW];
-#pragma unroll
-    for (int d = 0; d < PD; ++d)
-#pragma unroll
-      for (int j = 0; j < C::NW; ++j) wq[d][j] = wload(j, ch * NK + kord(d));
-    uint4 wsc[SC ? C::KS : 1][SC ? C::NW : 1];
-    if constexpr (SC) {
-      const unsigned char* scb = reinterpret_cast<const unsigned char*>(a.sc_wpack);
-#pragma unroll
-      for (int ks = 0; ks < C::KS; ++ks)
-#pragma unroll
-        for (int j = 0; j < C::NW; ++j) {
-          const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane(((nt0 + j * C::WN + wn) * (C::NCH * C::KS) + ch * C::KS + ks) * 1024);
-          wsc[ks][j] = *reinterpret_cast<const uint4*>(scb + soff + lane16);
-        }
-    }
+    if constexpr (!RESIDENT) load_weights(ch);
     __builtin_amdgcn_sched_barrier(0);  // keep the loads up here: the scheduler otherwise sinks them next to their use
     if (ch) __syncthreads();
     // stage the halo tile with LDS-DMA (global_load_lds_dwordx4: 64 lanes x 16 B land on 1 KiB of LDS, no VGPRs,
@@ -283,51 +304,78 @@ void conv3x3_kernel(ConvArgs a) {
     constexpr int CPR = NC * C::EB / 16;             // 16-B chunks per position
     constexpr int NIT = (C::MT * CPR + NTHREADS - 1) / NTHREADS;   // copy-out iterations per thread
     const unsigned char* scut = reinterpret_cast<const unsigned char*>(a.shortcut);
+    // persistent shapes keep 72 registers of weights alive through the epilogue: only the first half of the shortcut
+    // chunks is fetched ahead of the epilogue arithmetic, the second half once the accumulators are dead
+    constexpr int NPRE = (RESID && RESIDENT) ? (NIT + 1) / 2 : NIT;
     uint4 sreg[RESID ? NIT : 1];
+    auto fetch_shortcut = [&](int q) {
+      const int idx = tid + q * NTHREADS, m = idx / CPR, cc = idx % CPR;
+      return (idx < mvalid * CPR) ? *reinterpret_cast<const uint4*>(scut + ((gpos0 + m) * C::COUT + nt0 * 32 + j * NC) * C::EB + cc * 16)
+                                  : make_uint4(0, 0, 0, 0);
+    };
     if constexpr (RESID) {
 #pragma unroll
-      for (int q = 0; q < NIT; ++q) {
-        const int idx = tid + q * NTHREADS, m = idx / CPR, cc = idx % CPR;
-        sreg[q] = (idx < mvalid * CPR) ? *reinterpret_cast<const uint4*>(scut + ((gpos0 + m) * C::COUT + nt0 * 32 + j * NC) * C::EB + cc * 16)
-                                       : make_uint4(0, 0, 0, 0);
-      }
+      for (int q = 0; q < NPRE; ++q) sreg[q] = fetch_shortcut(q);
     }
-    float ssum[16];
+    float* sp = nullptr;
+    if constexpr (STATS) sp = se_part + (((size_t)b * tiles + tile) * C::WM + wm) * C::COUT + nbase + 4 * h;
+    float ssum[STATS ? 16 : 1];
+    if constexpr (STATS) {
 #pragma unroll
-    for (int q = 0; q < 16; ++q) ssum[q] = 0.f;
-    f32x4 sc[4], sh[4], gt[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      sc[g] = *reinterpret_cast<const f32x4*>(scale + nbase + 8 * g + 4 * h);
-      sh[g] = *reinterpret_cast<const f32x4*>(shift + nbase + 8 * g + 4 * h);
-      if constexpr (RESID) gt[g] = *reinterpret_cast<const f32x4*>(gate + (size_t)b * C::COUT + nbase + 8 * g + 4 * h);
+      for (int q = 0; q < 16; ++q) ssum[q] = 0.f;
     }
-#pragma unroll
-    for (int i = 0; i < C::MW; ++i) {
+    auto ld4 = [&](const float* p, int g) { return *reinterpret_cast<const f32x4*>(p + nbase + 8 * g + 4 * h); };
+    const float* gate_b = RESID ? gate + (size_t)b * C::COUT : scale;
+    // one (M-tile i, channel group g) cell: 4 values -> BN, gate or ReLU, rounding, plane sums, 8/16 B into the out tile
+    auto cell = [&](int i, int g, const f32x4& sc, const f32x4& sh, const f32x4& gt) {
       const int m = (wm * C::MW + i) * 32 + r;
       const bool valid = m < mvalid;
       unsigned char* lp = smem + m * OPS + (wn * 32 + 4 * h) * C::EB;
+      float v[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float x = accv[i][j][4 * g + q] * sc[q] + sh[q];
+        if constexpr (RESID) x *= gt[q];
+        else if (relu) x = relu_nan(x);
+        if constexpr (C::EB == 2) x = round_bf16(x);  // what is stored (and what the next conv reads)
+        v[q] = x;
+        if constexpr (STATS) ssum[4 * g + q] += valid ? x : 0.f;
+      }
+      if constexpr (C::EB == 2) *reinterpret_cast<uint2*>(lp + 8 * g * 2) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+      else *reinterpret_cast<float4*>(lp + 8 * g * 4) = make_float4(v[0], v[1], v[2], v[3]);
+    };
+    if constexpr (RESIDENT) {
+      // persistent shapes (72 registers of weights stay live): one channel group at a time, the next group's
+      // constants in flight while this one is processed -> 24 instead of 48 registers of constants
+      f32x4 sc_n = ld4(scale, 0), sh_n = ld4(shift, 0), gt_n = ld4(gate_b, 0);
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        float v[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          float x = accv[i][j][4 * g + q] * sc[g][q] + sh[g][q];
-          if constexpr (RESID) x *= gt[g][q];
-          else if (relu) x = relu_nan(x);
-          if constexpr (C::EB == 2) x = round_bf16(x);  // what is stored (and what the next conv reads)
-          v[q] = x;
-          if constexpr (STATS) ssum[4 * g + q] += valid ? x : 0.f;
+        const f32x4 sc = sc_n, sh = sh_n, gt = gt_n;
+        if (g + 1 < 4) {
+          sc_n = ld4(scale, g + 1);
+          sh_n = ld4(shift, g + 1);
+          if constexpr (RESID) gt_n = ld4(gate_b, g + 1);
         }
-        if constexpr (C::EB == 2) *reinterpret_cast<uint2*>(lp + 8 * g * 2) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
-        else *reinterpret_cast<float4*>(lp + 8 * g * 4) = make_float4(v[0], v[1], v[2], v[3]);
+#pragma unroll
+        for (int i = 0; i < C::MW; ++i) cell(i, g, sc, sh, gt);
       }
+    } else {
+      f32x4 sc[4], sh[4], gt[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        sc[g] = ld4(scale, g);
+        sh[g] = ld4(shift, g);
+        gt[g] = RESID ? ld4(gate_b, g) : sc[g];
+      }
+#pragma unroll
+      for (int i = 0; i < C::MW; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) cell(i, g, sc[g], sh[g], gt[g]);
     }
-    if constexpr (STATS) {
+    if constexpr (STATS) {  // sixteen independent DPP reductions after the arithmetic (per-group chains serialised it)
 #pragma unroll
       for (int q = 0; q < 16; ++q) ssum[q] = half_sum_upper_row(ssum[q]);
       if (r == 16) {
-        float* sp = se_part + (((size_t)b * tiles + tile) * C::WM + wm) * C::COUT + nbase + 4 * h;
 #pragma unroll
         for (int g = 0; g < 4; ++g)
           *reinterpret_cast<float4*>(sp + 8 * g) = make_float4(ssum[4 * g], ssum[4 * g + 1], ssum[4 * g + 2], ssum[4 * g + 3]);
@@ -364,6 +412,10 @@ void conv3x3_kernel(ConvArgs a) {
         eg[5 * C::COUT] = lds_elem(m0 + C::WOUT - 1, c);
       }
     }
+    if constexpr (RESID && NPRE < NIT) {
+#pragma unroll
+      for (int q = NPRE; q < NIT; ++q) sreg[q] = fetch_shortcut(q);
+    }
     if (!(a.dbg & 1)) {
 #pragma unroll
       for (int q = 0; q < NIT; ++q) {
@@ -393,13 +445,36 @@ void conv3x3_kernel(ConvArgs a) {
   emit(FormTag<FORM>{}, acc, a.scale, a.shift, reinterpret_cast<unsigned char*>(a.out), a.relu != 0);
   if constexpr (SC) emit(FormTag<FORM_PLAIN>{}, acc_sc, a.sc_scale, a.sc_shift, reinterpret_cast<unsigned char*>(a.sc_out), false);
   stamp(6);
+  return true;
+  };
+  if constexpr (RESIDENT) {
+    bool first_item = true;
+    for (int wi = blockIdx.x >> 3; wi < wcount; wi += wstride)
+      if (do_item(wfirst + wi, first_item)) first_item = false;
+  } else {  // one work item per workgroup (no loop: its invariants would cost these kernels registers)
+    if ((int)(blockIdx.x >> 3) < wcount) do_item(wfirst + (int)(blockIdx.x >> 3), true);
+  }
+}
+
+static int cu_count() {
+  static int n = 0;
+  if (!n) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v;
+    else n = 256;
+  }
+  return n;
 }
 
 template <class C>
 static int launch_cfg(const ConvArgs& a, hipStream_t st) {
-  const int tiles = cdiv(a.Hout, C::TH);
-  dim3 grid((unsigned)(a.B * tiles), C::COUT / C::NT);
-  const dim3 block(C::WM * C::WN * 64);
+  const int tiles = cdiv(a.Hout, C::TH), nwork = a.B * tiles;
+  // weight-resident shapes: just the workgroups the chip holds at once (LDS and the compiled-for occupancy), persistent
+  constexpr int NWV = C::WM * C::WN;
+  const int occ = (a.sc_wpack ? 1 : C::OCC) * 4 / NWV, by_lds = 160 * 1024 / C::LDS;
+  const int resident_wgs = cu_count() * (occ < by_lds ? (occ > 0 ? occ : 1) : by_lds);
+  dim3 grid((unsigned)((C::RESIDENT && !(a.dbg & 8) && nwork > resident_wgs) ? resident_wgs : nwork), C::COUT / C::NT);
+  const dim3 block(NWV * 64);
   SK_CHECK(!(a.gate && a.se_part), SK_EARG, "a convolution is either the statistics or the residual form");
   if constexpr (C::TAPS == 9 && C::NW == 1 && C::S == 2) {
     if (a.sc_wpack) {
