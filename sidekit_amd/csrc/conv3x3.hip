@@ -50,15 +50,17 @@ struct ConvCfg {
   //           lanes that read the zero page: 70 pieces for a layer1 tile of 51 KB.
   //  swizzled (SWZ = true): CB bytes per position, no pad slots; the 16-B chunk c of column p sits at slot c ^ f(p)
   //           (f below), which is as conflict-free as the padding and costs nothing to stage because a DMA lane may fetch any
-  //           global address; ONE zero position between rows (and before row 0) is both neighbours' zero column and is
-  //           written once by ds_write.  A row is WIN * CB bytes = whole pieces: 50 pieces for the same layer1 tile.
+  //           global address; ONE zero position after each row serves as the zero column on both sides (column -1 of a
+  //           row is read from that row's own trailing zero position) and is written by ds_write.  A row is WIN * CB
+  //           bytes = whole pieces: 50 pieces for the same layer1 tile, and a 128-channel layer3 tile is 10 x 5376 B =
+  //           53760 B = exactly 42 of the 1280-B LDS allocation granules, so three workgroups fit a CU.
   static constexpr bool SWZ = SWZ_;
   static constexpr int PSTRIDE = SWZ ? CB : CB + 16;
   static constexpr int SPP = PSTRIDE / 16;                // 16-B slots per staged position
   static constexpr int PPR = ((SWZ ? WIN : WP) * SPP + 63) / 64;   // 1-KiB LDS-DMA pieces per staged row
   static constexpr int RS = SWZ ? (WIN + 1) * CB : PPR * 1024;     // LDS row stride
-  static constexpr int ROW0 = SWZ ? CB : 0;               // offset of row 0 (swizzled: after the leading zero position)
-  static constexpr int LDS = SWZ ? ((ROW0 + (RIN - 1) * RS + PPR * 1024 + 1023) / 1024 * 1024) : RIN * RS;
+  static constexpr int LDS_SWZ = (RIN - 1) * RS + (PPR * 1024 > RS ? PPR * 1024 : RS);   // a masked partial last piece still addresses whole KiB
+  static constexpr int LDS = SWZ ? (LDS_SWZ + 255) / 256 * 256 : RIN * RS;
   static constexpr int SWF = SPP < 16 ? SPP : 16;         // swizzle period in slots
   static constexpr int SWSH = SPP == 4 ? 2 : (SPP == 8 ? 1 : 0);   // f(p) = (p >> SWSH) & (SWF - 1): 16 consecutive columns hit 16 distinct bank groups
   static_assert(!SWZ || (SPP == 4 || SPP == 8 || SPP == 16 || SPP == 32), "swizzled image: 64..512 B per position");
@@ -71,7 +73,9 @@ struct ConvCfg {
   static constexpr int NK = TAPS * KS;           // k-steps per channel chunk
   static constexpr int PD = PD_ ? PD_ : ((NK * NW <= 24) ? NK : (NW == 1 ? 8 : 4));   // weight prefetch depth in k-steps
   static constexpr bool RESIDENT = TAPS == 9 && NCH == 1 && PD == NK && NT == COUT;   // a wave keeps all its weight fragments in registers
-  static_assert(MT == WM * MW * 32, "positions must tile into 32-row MFMA tiles");
+  static constexpr bool LEAN = RESIDENT || OCC >= 3;   // register-lean epilogue (constants per channel group, shortcut prefetch in two halves)
+  static_assert(MT <= WM * MW * 32, "positions must be covered by the waves' 32-row MFMA tiles (trailing tiles may be partial or idle)");
+  static constexpr bool PARTIAL_M = MT < WM * MW * 32;   // lanes past the tile compute on a duplicate of the last position and store nothing
   static_assert(COUT % NT == 0 && CIN % CK == 0 && CB % 32 == 0, "channel tiling");
   static_assert(LDS <= 160 * 1024, "LDS budget");
 };
@@ -111,14 +115,15 @@ void conv3x3_kernel(ConvArgs a) {
   int base[C::MW][C::SWZ ? 3 : 1];
 #pragma unroll
   for (int i = 0; i < C::MW; ++i) {
-    const int m = (wm * C::MW + i) * 32 + r;
+    const int mraw = (wm * C::MW + i) * 32 + r, m = (C::PARTIAL_M && mraw >= C::MT) ? C::MT - 1 : mraw;
     const int ho = m / C::WOUT, wo = m % C::WOUT;
     if constexpr (C::SWZ) {
 #pragma unroll
       for (int dw = 0; dw < 3; ++dw) {
-        const int col = wo * C::S + dw - 1;   // -1 / WIN: the zero position before / after the row
+        int col = wo * C::S + dw - 1;
+        if (col < 0) col = C::WIN;            // column -1 and column WIN are both the row's trailing zero position
         const int f = (col >> C::SWSH) & (C::SWF - 1);
-        base[i][dw] = C::ROW0 + (ho * C::S) * C::RS + col * C::CB + ((h ^ f) << 4);
+        base[i][dw] = (ho * C::S) * C::RS + col * C::CB + ((h ^ f) << 4);
       }
     } else {
       base[i][0] = (ho * C::S) * C::RS + (wo * C::S) * C::PSTRIDE + h * 16;
@@ -201,9 +206,9 @@ void conv3x3_kernel(ConvArgs a) {
     // (measured: masking those lanes off and zero-filling with ds_write instead is 20 % slower).
     constexpr int CPP = C::CB / 16, NPIECE = C::RIN * C::PPR;
     if constexpr (C::SWZ) {
-      if (ch == 0) {  // the zero positions between rows: never touched by the DMA, valid for every channel chunk
-        for (int s = tid; s < (C::RIN + 1) * C::SPP; s += NTHREADS)
-          *reinterpret_cast<uint4*>(smem + (s / C::SPP) * C::RS + (s % C::SPP) * 16) = make_uint4(0, 0, 0, 0);
+      if (ch == 0) {  // the zero position after each row: never touched by the DMA, valid for every channel chunk
+        for (int s = tid; s < C::RIN * C::SPP; s += NTHREADS)
+          *reinterpret_cast<uint4*>(smem + (s / C::SPP) * C::RS + C::WIN * C::CB + (s % C::SPP) * 16) = make_uint4(0, 0, 0, 0);
       }
     }
     for (int it = (a.dbg & 4) ? NPIECE : wave; it < NPIECE; it += NWAVES) {
@@ -219,7 +224,7 @@ void conv3x3_kernel(ConvArgs a) {
         if (rowok) src = rowbase + col * (C::CIN * C::EB) + cc * 16;
         if ((C::WIN * C::SPP) % 64 == 0 || slot < C::WIN * C::SPP)  // a partial last piece must not run into the next row
           __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                           (__attribute__((address_space(3))) void*)(smem + C::ROW0 + row * C::RS + q * 1024), 16, 0, 0);
+                                           (__attribute__((address_space(3))) void*)(smem + row * C::RS + q * 1024), 16, 0, 0);
       } else {
         const int col = slot / C::SPP, cc = slot - col * C::SPP;
         if (rowok && cc < CPP && col >= 1 && col <= C::WIN) src = rowbase + (col - 1) * (C::CIN * C::EB) + cc * 16;
@@ -246,8 +251,8 @@ void conv3x3_kernel(ConvArgs a) {
     if (!(a.dbg & 2))
 #pragma unroll
     for (int kk = 0; kk < NK; ++kk) {
-      if (kk + 1 < NK) {  // the next k-step's activation fragments are read while this step's MFMAs run
-#pragma unroll
+      if (kk + 1 < NK && C::OCC < 3) {  // the next k-step's activation fragments are read while this step's MFMAs run
+#pragma unroll                           // (three waves per SIMD hide the LDS latency themselves and have no registers for it)
         for (int i = 0; i < C::MW; ++i) xn[i] = *reinterpret_cast<const uint4*>(xaddr(i, kk + 1));
       }
       uint4 wf[C::NW];
@@ -270,8 +275,13 @@ void conv3x3_kernel(ConvArgs a) {
             for (int j = 0; j < C::NW; ++j) mma_step<T>(acc_sc[i][j], wsc[step_ks(kk)][j], xc[i]);
         }
       }
+      if (kk + 1 < NK) {
 #pragma unroll
-      for (int i = 0; i < C::MW; ++i) xc[i] = xn[i];
+        for (int i = 0; i < C::MW; ++i) {
+          if constexpr (C::OCC < 3) xc[i] = xn[i];
+          else xc[i] = *reinterpret_cast<const uint4*>(xaddr(i, kk + 1));
+        }
+      }
     }
   }
 
@@ -306,7 +316,7 @@ void conv3x3_kernel(ConvArgs a) {
     const unsigned char* scut = reinterpret_cast<const unsigned char*>(a.shortcut);
     // persistent shapes keep 72 registers of weights alive through the epilogue: only the first half of the shortcut
     // chunks is fetched ahead of the epilogue arithmetic, the second half once the accumulators are dead
-    constexpr int NPRE = (RESID && RESIDENT) ? (NIT + 1) / 2 : NIT;
+    constexpr int NPRE = (RESID && C::LEAN) ? (NIT + 1) / 2 : NIT;
     uint4 sreg[RESID ? NIT : 1];
     auto fetch_shortcut = [&](int q) {
       const int idx = tid + q * NTHREADS, m = idx / CPR, cc = idx % CPR;
@@ -329,8 +339,9 @@ void conv3x3_kernel(ConvArgs a) {
     // one (M-tile i, channel group g) cell: 4 values -> BN, gate or ReLU, rounding, plane sums, 8/16 B into the out tile
     auto cell = [&](int i, int g, const f32x4& sc, const f32x4& sh, const f32x4& gt) {
       const int m = (wm * C::MW + i) * 32 + r;
-      const bool valid = m < mvalid;
+      const bool valid = m < mvalid;   // mvalid <= MT
       unsigned char* lp = smem + m * OPS + (wn * 32 + 4 * h) * C::EB;
+      const bool store = !C::PARTIAL_M || m < C::MT;
       float v[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -341,11 +352,13 @@ void conv3x3_kernel(ConvArgs a) {
         v[q] = x;
         if constexpr (STATS) ssum[4 * g + q] += valid ? x : 0.f;
       }
-      if constexpr (C::EB == 2) *reinterpret_cast<uint2*>(lp + 8 * g * 2) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
-      else *reinterpret_cast<float4*>(lp + 8 * g * 4) = make_float4(v[0], v[1], v[2], v[3]);
+      if (store) {
+        if constexpr (C::EB == 2) *reinterpret_cast<uint2*>(lp + 8 * g * 2) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+        else *reinterpret_cast<float4*>(lp + 8 * g * 4) = make_float4(v[0], v[1], v[2], v[3]);
+      }
     };
-    if constexpr (RESIDENT) {
-      // persistent shapes (72 registers of weights stay live): one channel group at a time, the next group's
+    if constexpr (C::LEAN) {
+      // persistent shapes (72 registers of weights stay live) and the three-workgroups-per-CU shapes (168 registers): one channel group at a time, the next group's
       // constants in flight while this one is processed -> 24 instead of 48 registers of constants
       f32x4 sc_n = ld4(scale, 0), sh_n = ld4(shift, 0), gt_n = ld4(gate_b, 0);
 #pragma unroll
@@ -475,6 +488,11 @@ static int launch_cfg(const ConvArgs& a, hipStream_t st) {
   const int resident_wgs = cu_count() * (occ < by_lds ? (occ > 0 ? occ : 1) : by_lds);
   dim3 grid((unsigned)((C::RESIDENT && !(a.dbg & 8) && nwork > resident_wgs) ? resident_wgs : nwork), C::COUT / C::NT);
   const dim3 block(NWV * 64);
+  if (a.dbg & 16) {  // tuning aid: what the runtime says about residency of the statistics-form kernel
+    int nb = -1;
+    if constexpr (C::TAPS == 9) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv3x3_kernel<C, false, FORM_STATS>, NWV * 64, 0);
+    fprintf(stderr, "[conv occupancy] LDS %d B, compiled for %d waves/SIMD: %d workgroups per CU\n", C::LDS, C::OCC, nb);
+  }
   SK_CHECK(!(a.gate && a.se_part), SK_EARG, "a convolution is either the statistics or the residual form");
   if constexpr (C::TAPS == 9 && C::NW == 1 && C::S == 2) {
     if (a.sc_wpack) {
@@ -507,25 +525,25 @@ static int launch_cfg(const ConvArgs& a, hipStream_t st) {
 
 // ---- the trunk's convolution shapes ---------------------------------------------------------
 //                      T      CIN COUT S WIN TH WM WN MW NW  CK TAPS
-using B_L1   = ConvCfg<bf16_t,  32,  32, 1, 80,  8, 4, 1, 5, 1, 32, 9, 0, 0, true>;
+using B_L1   = ConvCfg<bf16_t,  32,  32, 1, 80,  8, 4, 1, 5, 1, 32, 9, 3, 6, true>;     // three workgroups per CU (168 registers, 52 KB)
 using B_L1S  = ConvCfg<bf16_t,  32,  32, 1, 80,  8, 4, 1, 5, 1, 32, 1, 0, 0, true>;
 using B_L2A  = ConvCfg<bf16_t,  32,  64, 2, 80,  8, 2, 2, 5, 1, 32, 9, 0, 0, true>;
 using B_L2S  = ConvCfg<bf16_t,  32,  64, 2, 80,  8, 2, 2, 5, 1, 32, 1, 0, 0, true>;
-using B_L2   = ConvCfg<bf16_t,  64,  64, 1, 40,  8, 2, 2, 5, 1, 64, 9, 0, 0, true>;
+using B_L2   = ConvCfg<bf16_t,  64,  64, 1, 40,  8, 2, 2, 5, 1, 64, 9, 3, 4, true>;     // three workgroups per CU
 using B_L3A  = ConvCfg<bf16_t,  64, 128, 2, 40,  8, 1, 4, 5, 1, 64, 9>;
 using B_L3S  = ConvCfg<bf16_t,  64, 128, 2, 40,  8, 1, 4, 5, 1, 64, 1>;
-using B_L3   = ConvCfg<bf16_t, 128, 128, 1, 20,  8, 1, 4, 5, 1, 128, 9>;
+using B_L3   = ConvCfg<bf16_t, 128, 128, 1, 20,  8, 1, 4, 5, 1, 128, 9, 3, 4, true>;    // three workgroups per CU: 53760 B = 42 LDS granules
 using B_L4A  = ConvCfg<bf16_t, 128, 256, 2, 20, 16, 1, 4, 5, 1, 64, 9>;    // NT = 128: grid.y = 2, 80 accumulator registers
 using B_L4S  = ConvCfg<bf16_t, 128, 256, 2, 20, 16, 1, 4, 5, 1, 64, 1>;
 using B_L4   = ConvCfg<bf16_t, 256, 256, 1, 10, 16, 1, 4, 5, 1, 128, 9>;   // NT = 128: two workgroups per CU
 
 // tuning candidates (sk_bench_conv shapes 11..): smaller halo tiles, more workgroups per CU
-using B_X0   = ConvCfg<bf16_t,  32,  32, 1, 80,  8, 4, 1, 5, 1, 32, 9>;     // L1 swizzled image, 2 WGs/CU
+using B_X0   = ConvCfg<bf16_t,  32,  32, 1, 80,  8, 4, 1, 5, 1, 32, 9, 0, 0, true>;     // L1, two persistent weight-resident workgroups per CU
 using B_X1   = ConvCfg<bf16_t,  32,  64, 2, 80,  8, 2, 2, 5, 1, 32, 9>;     // L1 swizzled, 3 WGs/CU (168 registers)
-using B_X2   = ConvCfg<bf16_t,  64,  64, 1, 40,  8, 2, 2, 5, 1, 64, 9>;     // L2 swizzled
+using B_X2   = ConvCfg<bf16_t,  64,  64, 1, 40,  8, 2, 2, 5, 1, 64, 9, 0, 0, true>;     // L2, two workgroups per CU
 using B_X3   = ConvCfg<bf16_t,  32,  32, 1, 80,  8, 4, 1, 5, 1, 32, 1>;     // L2 swizzled, 3 WGs/CU
-using B_X4   = ConvCfg<bf16_t, 128, 128, 1, 20,  8, 1, 4, 5, 1, 128, 9, 2, 0, true>;    // L3 swizzled
-using B_X5   = ConvCfg<bf16_t, 256, 256, 1, 10, 16, 1, 4, 5, 1, 128, 9, 2, 0, true>;    // L4 swizzled (partial last piece)
+using B_X4   = ConvCfg<bf16_t, 128, 128, 1, 20,  8, 1, 4, 5, 1, 128, 9>;               // L3, padded image, two workgroups per CU
+using B_X5   = ConvCfg<bf16_t, 256, 256, 1, 10, 16, 1, 4, 5, 1, 128, 9, 3, 2, true>;    // L4 likewise
 using F_X4 = ConvCfg<float, 128, 128, 1, 20,  8, 1, 4, 5, 1, 128, 9>;
 using F_X5 = ConvCfg<float, 256, 256, 1, 10, 16, 1, 4, 5, 2, 128, 9>;
 using F_X0 = ConvCfg<float,  32,  32, 1, 80,  8, 4, 1, 5, 1, 32, 9>;

@@ -961,7 +961,7 @@ int sk_bench_conv(int32_t shape, int32_t dtype, int32_t B, int32_t T, int32_t it
   ConvArgs a;
   memset(&a, 0, sizeof(a));
   a.in = in; a.wpack = w; a.scale = sc; a.shift = sh; a.out = out; a.se_part = nullptr; a.zeros = zeros;
-  a.lens = Lens{nullptr, T}; a.halvings_in = 0; a.B = B; a.Hin = hin; a.Hout = hout; a.relu = 1; a.dbg = (variant & 7) | ((variant & 32) ? 8 : 0);
+  a.lens = Lens{nullptr, T}; a.halvings_in = 0; a.B = B; a.Hin = hin; a.Hout = hout; a.relu = 1; a.dbg = (variant & 7) | ((variant & 32) ? 8 : 0) | ((variant & 64) ? 16 : 0);
   const int nblk = B * cdiv(hout, g.th);
   unsigned long long* stamps = nullptr;
   float *gate = nullptr; void* scut = nullptr; float *colp = nullptr, *edge = nullptr;
