@@ -56,8 +56,8 @@ __host__ __device__ inline uint16_t f32_to_bf16(float f) {
   if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
   return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
 }
-// ReLU that lets NaN through like torch.relu (fmaxf would swallow it)
-__device__ inline float relu_nan(float x) { return x < 0.f ? 0.f : x; }
+// ReLU that lets NaN through like torch.relu (fmaxf would swallow it): IEEE-754-2019 maximum = one v_maximum3_f32 on gfx950
+__device__ inline float relu_nan(float x) { return __builtin_elementwise_maximum(x, 0.f); }
 // device-side conversions use the hardware v_cvt_pk_bf16_f32 (round-to-nearest-even, NaN stays NaN): the integer
 // formulation above costs ~8 VALU per value, which made the conv epilogues VALU-bound (measured with in-kernel stamps)
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));

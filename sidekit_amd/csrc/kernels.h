@@ -56,7 +56,8 @@ int launch_stem(const float* feats, long sb, long sf, long st, const float* w /*
 struct SeArgs {
   const float* se_part; const float* col_part; const float* edge;   // as written by the statistics-mode conv
   int tiles, wm, th;
-  const float* w2t;      // conv2 weights as consumed by the MFMA (bf16-rounded in the bf16 path), [tap][ci][co] f32
+  const void* w2t;       // conv2 weights as consumed by the MFMA, [tap][ci][co]: bf16 in the bf16 path (w2t_bf16), else f32
+  int w2t_bf16;
   const float* scale2; const float* shift2;
   const float* fc1; const float* fc2;   // se.fc.0 [C/16][C], se.fc.2 [C][C/16]
   float* gate;           // [B][C]

@@ -73,13 +73,17 @@ int launch_stem(const float* feats, long sb, long sf, long st, const float* w, c
 }
 
 // ---- SE gate from conv1's output sums -----------------------------------------------------------------
-// One workgroup per utterance, one thread per channel.  Partial sums are added in a fixed order (tile, wave) so the
-// result is bitwise reproducible.  For the tap shifted by (dh, dw) the sum of the shifted, zero-padded plane is
+// One workgroup (1024 threads) per utterance.  Partial sums are added in a fixed order (tile, wave) so the result is
+// bitwise reproducible.  For the tap shifted by (dh, dw) the sum of the shifted, zero-padded plane is
 //   S = T - R(excluded border row) - C(excluded border column) + corner(both excluded).
-// 1024 threads = G groups of C channels: the groups split the tile range and the (tap, ci) range, partial results
-// are combined through LDS in group order.
+// Phase 1 (thread = channel x tile group) reduces conv1's per-tile sums to S[9][C]; phase 2 contracts S with conv2's
+// weights: a thread owns 16 B of consecutive output channels (8 bf16 / 4 f32) and every KG-th (tap, ci) row, so the
+// 9*C*C weights stream as whole 16-B loads (one 2/4-B load per FMA was latency-bound: 55 us at C = 256), partial
+// sums meet in LDS in row-group order; phase 3 is the two small FC layers and the sigmoid.
+template <typename WT>
 __global__ __launch_bounds__(1024) void se_pre_kernel(SeArgs a) {
-  __shared__ float red[3 * 1024];
+  constexpr int VEC = 16 / sizeof(WT);
+  __shared__ float red[8 * 1024];   // phase 1: 3 x 1024; phase 2: [KG][C] partial sums (KG * C = 1024 * VEC / ... <= 8192)
   __shared__ float S[9 * 256];
   __shared__ float y[256];
   __shared__ float hid[16];
@@ -111,15 +115,35 @@ __global__ __launch_bounds__(1024) void se_pre_kernel(SeArgs a) {
       }
   }
   __syncthreads();
-  float m = 0.f;
-#pragma unroll 8
-  for (int k = g; k < 9 * C; k += G) m = fmaf(a.w2t[(size_t)k * C + c], S[k], m);   // k = tap * C + ci
-  red[threadIdx.x] = m;
-  __syncthreads();
-  if (g == 0) {
-    m = 0.f;
-    for (int q = 0; q < G; ++q) m += red[q * C + c];
-    y[c] = m / (float)(hb * a.wout) * a.scale2[c] + a.shift2[c];
+  {
+    const int CG = C / VEC, KG = 1024 / CG, cg = threadIdx.x % CG, kg = threadIdx.x / CG;
+    float m[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) m[v] = 0.f;
+    const unsigned char* wp = reinterpret_cast<const unsigned char*>(a.w2t) + (size_t)cg * 16;
+#pragma unroll 4
+    for (int k = kg; k < 9 * C; k += KG) {   // k = tap * C + ci
+      const uint4 w = *reinterpret_cast<const uint4*>(wp + (size_t)k * C * sizeof(WT));
+      const float s = S[k];
+      const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if constexpr (sizeof(WT) == 2) {
+          m[2 * q] = fmaf(bf16_to_f32((uint16_t)(ww[q] & 0xffff)), s, m[2 * q]);
+          m[2 * q + 1] = fmaf(bf16_to_f32((uint16_t)(ww[q] >> 16)), s, m[2 * q + 1]);
+        } else {
+          m[q] = fmaf(__builtin_bit_cast(float, ww[q]), s, m[q]);
+        }
+      }
+    }
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) red[kg * C + cg * VEC + v] = m[v];   // KG * C = 1024 * VEC floats
+    __syncthreads();
+    if (g == 0) {
+      float t = 0.f;
+      for (int q = 0; q < KG; ++q) t += red[q * C + c];
+      y[c] = t / (float)(hb * a.wout) * a.scale2[c] + a.shift2[c];
+    }
   }
   __syncthreads();
   const int R = C / 16;
@@ -138,7 +162,8 @@ __global__ __launch_bounds__(1024) void se_pre_kernel(SeArgs a) {
 
 int launch_se_pre(const SeArgs& a, hipStream_t s) {
   SK_CHECK(a.C <= 256 && a.C % 16 == 0 && 1024 % a.C == 0, SK_EARG, "se_pre: C=%d unsupported", a.C);
-  hipLaunchKernelGGL(se_pre_kernel, dim3(a.B), dim3(1024), 0, s, a);
+  if (a.w2t_bf16) hipLaunchKernelGGL(se_pre_kernel<uint16_t>, dim3(a.B), dim3(1024), 0, s, a);
+  else hipLaunchKernelGGL(se_pre_kernel<float>, dim3(a.B), dim3(1024), 0, s, a);
   SK_HIP(hipGetLastError());
   return SK_OK;
 }

@@ -46,7 +46,7 @@ struct Block {
   bool has_sc = false;
   float* se_w1 = nullptr;
   float* se_w2 = nullptr;
-  float* w2t = nullptr;  // conv2 weights as the MFMA consumes them, [tap][ci][co] f32 (SE gate pre-computation)
+  void* w2t = nullptr;   // conv2 weights as the MFMA consumes them, [tap][ci][co] bf16 / f32 (SE gate pre-computation)
   int C, li;
 };
 
@@ -319,14 +319,18 @@ static int finalize_half(xt_handle* h) {
         const auto& w2 = T(h, p + ".conv2.weight");  // [co][ci][3][3]
         const int Cb = b.C;
         std::vector<float> w2t((size_t)9 * Cb * Cb);
-        const bool bf = h->cfg.dtype == XT_BF16;
         for (int co = 0; co < Cb; ++co)
           for (int ci = 0; ci < Cb; ++ci)
-            for (int t = 0; t < 9; ++t) {
-              const float v = w2[((size_t)co * Cb + ci) * 9 + t];
-              w2t[((size_t)t * Cb + ci) * Cb + co] = bf ? bf16_to_f32(f32_to_bf16(v)) : v;
-            }
-        SK_TRY(upload_f(h, w2t, &b.w2t));
+            for (int t = 0; t < 9; ++t) w2t[((size_t)t * Cb + ci) * Cb + co] = w2[((size_t)co * Cb + ci) * 9 + t];
+        if (h->cfg.dtype == XT_BF16) {  // exactly the rounded weights the conv multiplies with
+          std::vector<uint16_t> hb(w2t.size());
+          for (size_t i = 0; i < w2t.size(); ++i) hb[i] = f32_to_bf16(w2t[i]);
+          SK_TRY(upload(h, hb.data(), hb.size() * 2, &b.w2t));
+        } else {
+          float* d = nullptr;
+          SK_TRY(upload_f(h, w2t, &d));
+          b.w2t = d;
+        }
       }
       SK_TRY(upload_f(h, T(h, p + ".se.fc.0.weight"), &b.se_w1));
       SK_TRY(upload_f(h, T(h, p + ".se.fc.2.weight"), &b.se_w2));
@@ -593,7 +597,7 @@ static int half_from_feats(xt_handle* h, const float* feats, long sb, long sf, l
     {  // SE gate, known before conv2 runs (linearity of the plane mean in O1)
       SeArgs se;
       se.se_part = (const float*)h->ws_se.p; se.col_part = (const float*)h->ws_col.p; se.edge = (const float*)h->ws_edge.p;
-      se.tiles = cdiv(Hl[li], b.c1.g.th); se.wm = b.c1.g.wm; se.th = b.c1.g.th; se.w2t = b.w2t; se.scale2 = b.c2.scale; se.shift2 = b.c2.shift;
+      se.tiles = cdiv(Hl[li], b.c1.g.th); se.wm = b.c1.g.wm; se.th = b.c1.g.th; se.w2t = b.w2t; se.w2t_bf16 = h->cfg.dtype == XT_BF16; se.scale2 = b.c2.scale; se.shift2 = b.c2.shift;
       se.fc1 = b.se_w1; se.fc2 = b.se_w2; se.gate = (float*)h->ws_gate.p; se.lens = m.lens; se.halvings = li; se.wout = wout; se.C = b.C; se.B = B;
       ProfScope ps(h, XT_PROF_SE_RES, st);
       SK_TRY(launch_se_pre(se, st));
