@@ -83,8 +83,9 @@ struct ConvCfg {
 // second launch-bound = waves per SIMD: two workgroups per CU whenever two halo tiles fit the LDS, which caps the
 // kernel at 256 registers (VGPR + AGPR) per lane
 // FORM selects the epilogue at compile time (the statistics form carries no shortcut registers, the residual form no
-// plane sums): 0 plain, 1 statistics (conv1 of a block), 2 residual (conv2 of a block)
-enum { FORM_PLAIN = 0, FORM_STATS = 1, FORM_RESID = 2 };
+// plane sums): 0 plain, 1 statistics (conv1 of a block), 2 residual (conv2 of a block), 3 residual with the layer's
+// first-block 1x1 shortcut convolution evaluated in the epilogue
+enum { FORM_PLAIN = 0, FORM_STATS = 1, FORM_RESID = 2, FORM_RESID_SC = 3 };   // 3: residual form, 1x1 shortcut conv computed in place
 template <int F> struct FormTag { static constexpr int value = F; };
 
 template <class C, bool SC, int FORM>
@@ -304,7 +305,8 @@ void conv3x3_kernel(ConvArgs a) {
   // one output stream: (accumulators, BN scale/shift, destination, epilogue form)
   auto emit = [&](auto form, auto& accv, const float* scale, const float* shift, unsigned char* out, bool relu) {
   constexpr bool STATS = decltype(form)::value == FORM_STATS, RESID = decltype(form)::value == FORM_RESID;
-  const float* gate = RESID ? a.gate : nullptr;
+  constexpr bool RSC = decltype(form)::value == FORM_RESID_SC;
+  const float* gate = (RESID || RSC) ? a.gate : nullptr;
   float* se_part = STATS ? a.se_part : nullptr;
 #pragma unroll
   for (int j = 0; j < C::NW; ++j) {
@@ -335,7 +337,7 @@ void conv3x3_kernel(ConvArgs a) {
       for (int q = 0; q < 16; ++q) ssum[q] = 0.f;
     }
     auto ld4 = [&](const float* p, int g) { return *reinterpret_cast<const f32x4*>(p + nbase + 8 * g + 4 * h); };
-    const float* gate_b = RESID ? gate + (size_t)b * C::COUT : scale;
+    const float* gate_b = (RESID || RSC) ? gate + (size_t)b * C::COUT : scale;
     // one (M-tile i, channel group g) cell: 4 values -> BN, gate or ReLU, rounding, plane sums, 8/16 B into the out tile
     auto cell = [&](int i, int g, const f32x4& sc, const f32x4& sh, const f32x4& gt) {
       const int m = (wm * C::MW + i) * 32 + r;
@@ -357,7 +359,78 @@ void conv3x3_kernel(ConvArgs a) {
         else *reinterpret_cast<float4*>(lp + 8 * g * 4) = make_float4(v[0], v[1], v[2], v[3]);
       }
     };
-    if constexpr (C::LEAN) {
+    if constexpr (RSC) {
+      // first block of a layer: x = bn2(conv2) * gate + bn_s(conv1x1_s(block input)); the 1x1 conv runs here on the
+      // matrix cores with the block input's rows as the position operand, read straight from global memory (a lane's
+      // fragment is 16 B of its own position, exactly the layout the halo tile has in LDS)
+      constexpr int SS = C::COUT == 32 ? 1 : 2, CX = C::COUT == 32 ? 32 : C::COUT / 2;   // the trunk's shortcut geometry
+      constexpr int KX = CX * C::EB / 32;                                               // k-steps of the 1x1
+      const unsigned char* xin = reinterpret_cast<const unsigned char*>(a.sc_in);
+      const unsigned char* scb = reinterpret_cast<const unsigned char*>(a.sc_wpack);
+      uint4 wx[KX];
+#pragma unroll
+      for (int ks = 0; ks < KX; ++ks) {
+        const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane(((nt0 + j * C::WN + wn) * KX + ks) * 1024);
+        wx[ks] = *reinterpret_cast<const uint4*>(scb + soff + (unsigned)lane * 16u);
+      }
+      // constants first (vector-memory loads return in order: a constant fetched between the position loads below
+      // would wait behind them), then the block-input fragments one M-tile ahead of their use
+      f32x4 k1[4], k0[4], s2[4], h2[4];   // bn2 scale * gate, bn2 shift * gate, shortcut BN scale / shift
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 sc = ld4(scale, g), sh = ld4(shift, g), gt = ld4(gate_b, g);
+        s2[g] = ld4(a.sc_scale, g);
+        h2[g] = ld4(a.sc_shift, g);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { k1[g][q] = sc[q] * gt[q]; k0[g][q] = sh[q] * gt[q]; }
+      }
+      constexpr bool AHEAD = KX <= 4;
+      auto xload = [&](int i, uint4* dst) {
+        const int m = (wm * C::MW + i) * 32 + r;
+        const int ho = m / C::WOUT, wo = m % C::WOUT;
+        const unsigned char* xp = xin + ((((size_t)b * a.sc_hin + (size_t)(ho0 + ho) * SS) * (C::WOUT * SS) + wo * SS) * CX) * C::EB + h * 16;
+#pragma unroll
+        for (int ks = 0; ks < KX; ++ks) dst[ks] = (m < mvalid) ? *reinterpret_cast<const uint4*>(xp + ks * 32) : make_uint4(0, 0, 0, 0);
+      };
+      uint4 xf[KX], xn[AHEAD ? KX : 1];
+      xload(0, xf);
+#pragma unroll
+      for (int i = 0; i < C::MW; ++i) {
+        const int m = (wm * C::MW + i) * 32 + r;
+        if constexpr (AHEAD) { if (i + 1 < C::MW) xload(i + 1, xn); }
+        f32x16 t;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t[q] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KX; ++ks) mma_step<T>(t, wx[ks], xf[ks]);
+        if (i + 1 < C::MW) {
+          if constexpr (AHEAD) {
+#pragma unroll
+            for (int ks = 0; ks < KX; ++ks) xf[ks] = xn[ks];
+          } else {
+            xload(i + 1, xf);
+          }
+        }
+        unsigned char* lp = smem + m * OPS + (wn * 32 + 4 * h) * C::EB;
+        const bool store = !C::PARTIAL_M || m < C::MT;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          float v[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            // both addends are rounded to the storage type first, as when the shortcut is a stored tensor
+            float main_v = accv[i][j][4 * g + q] * k1[g][q] + k0[g][q];
+            float sc_v = t[4 * g + q] * s2[g][q] + h2[g][q];
+            if constexpr (C::EB == 2) { main_v = round_bf16(main_v); sc_v = round_bf16(sc_v); }
+            v[q] = relu_nan(main_v + sc_v);
+          }
+          if (store) {
+            if constexpr (C::EB == 2) *reinterpret_cast<uint2*>(lp + 8 * g * 2) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+            else *reinterpret_cast<float4*>(lp + 8 * g * 4) = make_float4(v[0], v[1], v[2], v[3]);
+          }
+        }
+      }
+    } else if constexpr (C::LEAN) {
       // persistent shapes (72 registers of weights stay live) and the three-workgroups-per-CU shapes (168 registers): one channel group at a time, the next group's
       // constants in flight while this one is processed -> 24 instead of 48 registers of constants
       f32x4 sc_n = ld4(scale, 0), sh_n = ld4(shift, 0), gt_n = ld4(gate_b, 0);
@@ -587,7 +660,33 @@ int conv_geom(int shape, int dtype, ConvGeom* g) {
   return SK_EARG;
 }
 
+// residual form with the in-place 1x1 shortcut (first block of a layer): four launches per forward, on the
+// two-workgroups-per-CU configurations (the epilogue holds the shortcut accumulators next to the main ones)
+using B_L1Z = ConvCfg<bf16_t,  32,  32, 1, 80,  8, 4, 1, 5, 1, 32, 9, 2, 6, true>;
+using B_L2Z = ConvCfg<bf16_t,  64,  64, 1, 40,  8, 2, 2, 5, 1, 64, 9, 2, 0, true>;
+using B_L3Z = ConvCfg<bf16_t, 128, 128, 1, 20,  8, 1, 4, 5, 1, 128, 9>;
+using B_L4Z = B_L4;
+
+template <class C>
+static int launch_rsc(const ConvArgs& a, hipStream_t st) {
+  SK_CHECK(a.gate && a.sc_wpack && a.sc_scale && a.sc_shift && !a.se_part && !a.shortcut, SK_EARG, "in-place shortcut form: bad arguments");
+  const int tiles = cdiv(a.Hout, C::TH);
+  hipLaunchKernelGGL((conv3x3_kernel<C, false, FORM_RESID_SC>), dim3((unsigned)(a.B * tiles), C::COUT / C::NT), dim3(C::WM * C::WN * 64), 0, st, a);
+  SK_HIP(hipGetLastError());
+  return SK_OK;
+}
+
 int launch_conv(int shape, int dtype, const ConvArgs& a, hipStream_t st) {
+  if (a.sc_in) {
+    switch (shape) {
+      case CONV_L1: return dtype == DT_BF16 ? launch_rsc<B_L1Z>(a, st) : launch_rsc<F_L1>(a, st);
+      case CONV_L2: return dtype == DT_BF16 ? launch_rsc<B_L2Z>(a, st) : launch_rsc<F_L2>(a, st);
+      case CONV_L3: return dtype == DT_BF16 ? launch_rsc<B_L3Z>(a, st) : launch_rsc<F_L3>(a, st);
+      case CONV_L4: return dtype == DT_BF16 ? launch_rsc<B_L4Z>(a, st) : launch_rsc<F_L4>(a, st);
+    }
+    set_error("launch_conv: shape %d has no in-place shortcut form", shape);
+    return SK_EARG;
+  }
   switch (shape) {
 #define X(id, name) \
   case id: return dtype == DT_BF16 ? launch_cfg<B_##name>(a, st) : launch_cfg<F_##name>(a, st);

@@ -29,6 +29,10 @@ struct ConvArgs {
   const void* sc_wpack; const float* sc_scale; const float* sc_shift; void* sc_out;
   const float* gate;   // [B][COUT]
   const void* shortcut;  // NHWC, same shape and type as out
+  // -- residual mode of the FIRST block of a layer (gate != nullptr && sc_in != nullptr): the shortcut is not a stored
+  //    tensor but bn(conv1x1_stride(x)) of the block input x (res_net.py:301-307), computed in this epilogue from x's
+  //    own rows: sc_in = x [B][sc_hin][WOUT*s][cin_x], weights sc_wpack / sc_scale / sc_shift
+  const void* sc_in; int sc_hin;
   const void* zeros;   // >= 16 zero bytes in device memory (source of the conv zero padding)
   Lens lens;           // feature frames per utterance
   int halvings_in;     // stride-2 stages between the features and this conv's input

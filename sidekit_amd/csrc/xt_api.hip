@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "../../include/sidekit_amd.h"
+#include <stdlib.h>
 #include "kernels.h"
 
 namespace sk {
@@ -69,6 +70,7 @@ struct DevBuf {
 using namespace sk;
 
 struct xt_handle {
+  bool shortcut_tensor = getenv("SIDEKIT_AMD_SHORTCUT_TENSOR") != nullptr;   // A/B switch, see half_from_feats
   xt_config cfg;
   int device = 0;
   bool finalized = false;
@@ -584,12 +586,16 @@ static int half_from_feats(xt_handle* h, const float* feats, long sb, long sf, l
     a.se_part = (float*)h->ws_se.p; a.col_part = (float*)h->ws_col.p; a.edge = (float*)h->ws_edge.p;
     a.halvings_in = lin; a.Hin = Hl[lin]; a.Hout = Hl[li]; a.relu = 1;
     // shortcut rides on conv1's centre tap where that costs no occupancy (the stride-2 shapes already run one workgroup per CU)
-    const bool fuse_sc = first && b.c1.g.stride == 2 && b.c1.g.nw == 1 && b.sc.g.ck == b.c1.g.ck;
+    // first block of a layer: by default conv2's epilogue evaluates the 1x1 shortcut conv itself from the block input
+    // (no shortcut tensor at all); the older forms -- riding on conv1's centre tap, or a separate 1x1 launch -- remain
+    // for A/B runs (SIDEKIT_AMD_SHORTCUT_TENSOR=1)
+    const bool inplace_sc = first && !h->shortcut_tensor;
+    const bool fuse_sc = first && !inplace_sc && b.c1.g.stride == 2 && b.c1.g.nw == 1 && b.sc.g.ck == b.c1.g.ck;
     if (fuse_sc) { a.sc_wpack = b.sc.wpack; a.sc_scale = b.sc.scale; a.sc_shift = b.sc.shift; a.sc_out = SC; }
     { ProfScope ps(h, b.c1.shape, st); SK_TRY(launch_conv(b.c1.shape, dt, a, st)); }
     a.sc_wpack = nullptr;
     const void* shortcut = first ? SC : X;
-    if (first && !fuse_sc) {  // 1x1 conv (stride s) + bn on the block input
+    if (first && !fuse_sc && !inplace_sc) {  // 1x1 conv (stride s) + bn on the block input
       a.wpack = b.sc.wpack; a.scale = b.sc.scale; a.shift = b.sc.shift; a.out = SC;
       a.se_part = nullptr; a.col_part = nullptr; a.edge = nullptr; a.relu = 0;
       { ProfScope ps(h, b.sc.shape, st); SK_TRY(launch_conv(b.sc.shape, dt, a, st)); }
@@ -606,6 +612,10 @@ static int half_from_feats(xt_handle* h, const float* feats, long sb, long sf, l
     a.in = O1; a.wpack = b.c2.wpack; a.scale = b.c2.scale; a.shift = b.c2.shift; a.out = O2;
     a.se_part = nullptr; a.col_part = nullptr; a.edge = nullptr; a.gate = (const float*)h->ws_gate.p; a.shortcut = shortcut;
     a.halvings_in = li; a.Hin = Hl[li]; a.Hout = Hl[li]; a.relu = 0;
+    if (inplace_sc) {
+      a.shortcut = nullptr; a.sc_in = X; a.sc_hin = Hl[lin];
+      a.sc_wpack = b.sc.wpack; a.sc_scale = b.sc.scale; a.sc_shift = b.sc.shift;
+    }
     { ProfScope ps(h, b.c2.shape, st); SK_TRY(launch_conv(b.c2.shape, dt, a, st)); }
     std::swap(X, O2);
     const bool last_of_layer = (bi + 1 == h->blocks.size()) || (h->blocks[bi + 1].li != li);
