@@ -47,9 +47,10 @@ def halve(h, n):
 
 # launches per forward of each shape in its two epilogue forms: (conv1 of a block: in -> out [+ fused 1x1 shortcut out],
 # conv2 of a block: in + shortcut -> out), see DESIGN.md section 4
-CONV_FORMS = {"conv_L1": (3, 3), "conv_L1S": (1, 0), "conv_L2A": (1, 0), "conv_L2S": (1, 0), "conv_L2": (3, 4), "conv_L3A": (1, 0),
-              "conv_L3S": (1, 0), "conv_L3": (5, 6), "conv_L4A": (1, 0), "conv_L4S": (1, 0), "conv_L4": (2, 3)}
-FUSED_SHORTCUT = ("conv_L2A", "conv_L3A", "conv_L4A")   # these launches also write the bn(conv1x1) shortcut tensor
+# launches per forward as (statistics form, residual form, residual form with the in-place 1x1 shortcut of a layer's first block)
+CONV_FORMS = {"conv_L1": (3, 2, 1), "conv_L2A": (1, 0, 0), "conv_L2": (3, 3, 1), "conv_L3A": (1, 0, 0), "conv_L3": (5, 5, 1),
+              "conv_L4A": (1, 0, 0), "conv_L4": (2, 2, 1),
+              "conv_L1S": (1, 0, 0), "conv_L2S": (1, 0, 0), "conv_L3S": (1, 0, 0), "conv_L4S": (1, 0, 0)}   # A/B path only
 
 
 def conv_work(name, B, T, eb):
@@ -57,14 +58,14 @@ def conv_work(name, B, T, eb):
     (every tensor the launch must read or write once)."""
     cin, cout, s, win, taps, lin, lout = CONV_SHAPES[name]
     hin, hout, wout = halve(T, lin), halve(T, lout), win // s
-    n1, n2 = CONV_FORMS[name]
+    n1, n2, n3 = CONV_FORMS[name]
     in_b, out_b = B * hin * win * cin * eb, B * hout * wout * cout * eb
     flops = 2.0 * B * hout * wout * cout * cin * taps
-    extra = out_b if name in FUSED_SHORTCUT else 0          # second output stream
-    if name in FUSED_SHORTCUT:
-        flops += 2.0 * B * hout * wout * cout * cin          # the centre-tap 1x1
-    nbytes = (n1 * (in_b + out_b + extra) + n2 * (in_b + 2 * out_b)) / (n1 + n2) + cout * cin * taps * eb
-    return flops, nbytes
+    cx = 32 if cout == 32 else cout // 2                      # channels of the block input the in-place shortcut reads
+    sc_in_b, sc_flops = B * hout * wout * cx * eb, 2.0 * B * hout * wout * cout * cx
+    n = n1 + n2 + n3
+    nbytes = (n1 * (in_b + out_b) + n2 * (in_b + 2 * out_b) + n3 * (in_b + out_b + sc_in_b + cout * cx * eb)) / n + cout * cin * taps * eb
+    return flops + n3 * sc_flops / n, nbytes
 
 
 def roofline(prof, B, T, dtype):

@@ -467,6 +467,10 @@ void conv3x3_kernel(ConvArgs a) {
           *reinterpret_cast<float4*>(sp + 8 * g) = make_float4(ssum[4 * g], ssum[4 * g + 1], ssum[4 * g + 2], ssum[4 * g + 3]);
       }
     }
+    if constexpr (RESID && NPRE < NIT) {  // accumulators are dead: the second half of the shortcut rides out the barrier
+#pragma unroll
+      for (int q = NPRE; q < NIT; ++q) sreg[q] = fetch_shortcut(q);
+    }
     if (j == 0) stamp(4);
     __syncthreads();  // out sub-tile complete
     if (j == 0) stamp(5);
@@ -497,10 +501,6 @@ void conv3x3_kernel(ConvArgs a) {
         eg[4 * C::COUT] = lds_elem(m0, c);
         eg[5 * C::COUT] = lds_elem(m0 + C::WOUT - 1, c);
       }
-    }
-    if constexpr (RESID && NPRE < NIT) {
-#pragma unroll
-      for (int q = NPRE; q < NIT; ++q) sreg[q] = fetch_shortcut(q);
     }
     if (!(a.dbg & 1)) {
 #pragma unroll
@@ -598,7 +598,7 @@ static int launch_cfg(const ConvArgs& a, hipStream_t st) {
 
 // ---- the trunk's convolution shapes ---------------------------------------------------------
 //                      T      CIN COUT S WIN TH WM WN MW NW  CK TAPS
-using B_L1   = ConvCfg<bf16_t,  32,  32, 1, 80,  8, 4, 1, 5, 1, 32, 9, 3, 6, true>;     // three workgroups per CU (168 registers, 52 KB)
+using B_L1   = ConvCfg<bf16_t,  32,  32, 1, 80,  8, 4, 1, 5, 1, 32, 9, 0, 0, true>;     // two persistent weight-resident workgroups per CU
 using B_L1S  = ConvCfg<bf16_t,  32,  32, 1, 80,  8, 4, 1, 5, 1, 32, 1, 0, 0, true>;
 using B_L2A  = ConvCfg<bf16_t,  32,  64, 2, 80,  8, 2, 2, 5, 1, 32, 9, 0, 0, true>;
 using B_L2S  = ConvCfg<bf16_t,  32,  64, 2, 80,  8, 2, 2, 5, 1, 32, 1, 0, 0, true>;
@@ -611,7 +611,7 @@ using B_L4S  = ConvCfg<bf16_t, 128, 256, 2, 20, 16, 1, 4, 5, 1, 64, 1>;
 using B_L4   = ConvCfg<bf16_t, 256, 256, 1, 10, 16, 1, 4, 5, 1, 128, 9>;   // NT = 128: two workgroups per CU
 
 // tuning candidates (sk_bench_conv shapes 11..): smaller halo tiles, more workgroups per CU
-using B_X0   = ConvCfg<bf16_t,  32,  32, 1, 80,  8, 4, 1, 5, 1, 32, 9, 0, 0, true>;     // L1, two persistent weight-resident workgroups per CU
+using B_X0   = ConvCfg<bf16_t,  32,  32, 1, 80,  8, 4, 1, 5, 1, 32, 9, 3, 6, true>;     // L1 at three workgroups per CU (weights not resident)
 using B_X1   = ConvCfg<bf16_t,  32,  64, 2, 80,  8, 2, 2, 5, 1, 32, 9>;     // L1 swizzled, 3 WGs/CU (168 registers)
 using B_X2   = ConvCfg<bf16_t,  64,  64, 1, 40,  8, 2, 2, 5, 1, 64, 9, 0, 0, true>;     // L2, two workgroups per CU
 using B_X3   = ConvCfg<bf16_t,  32,  32, 1, 80,  8, 4, 1, 5, 1, 32, 1>;     // L2 swizzled, 3 WGs/CU
