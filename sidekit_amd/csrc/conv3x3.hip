@@ -606,18 +606,18 @@ using B_L2   = ConvCfg<bf16_t,  64,  64, 1, 40,  8, 2, 2, 5, 1, 64, 9, 3, 4, tru
 using B_L3A  = ConvCfg<bf16_t,  64, 128, 2, 40,  8, 1, 4, 5, 1, 64, 9>;
 using B_L3S  = ConvCfg<bf16_t,  64, 128, 2, 40,  8, 1, 4, 5, 1, 64, 1>;
 using B_L3   = ConvCfg<bf16_t, 128, 128, 1, 20,  8, 1, 4, 5, 1, 128, 9, 3, 4, true>;    // three workgroups per CU: 53760 B = 42 LDS granules
-using B_L4A  = ConvCfg<bf16_t, 128, 256, 2, 20, 16, 1, 4, 5, 1, 64, 9>;    // NT = 128: grid.y = 2, 80 accumulator registers
+using B_L4A  = ConvCfg<bf16_t, 128, 256, 2, 20, 17, 1, 4, 6, 1, 64, 9>;    // 17-row tiles: T' = 51 = 3 x 17 at the 4 s benchmark length (16-row tiles computed 64 rows); NT = 128: grid.y = 2
 using B_L4S  = ConvCfg<bf16_t, 128, 256, 2, 20, 16, 1, 4, 5, 1, 64, 1>;
-using B_L4   = ConvCfg<bf16_t, 256, 256, 1, 10, 16, 1, 4, 5, 1, 128, 9>;   // NT = 128: two workgroups per CU
+using B_L4   = ConvCfg<bf16_t, 256, 256, 1, 10, 17, 1, 4, 6, 1, 128, 9, 2>;   // 170 of 192 M-tile slots used; NT = 128: two workgroups per CU
 
 // tuning candidates (sk_bench_conv shapes 11..): smaller halo tiles, more workgroups per CU
 using B_X0   = ConvCfg<bf16_t,  32,  32, 1, 80,  8, 4, 1, 5, 1, 32, 9, 3, 6, true>;     // L1 at three workgroups per CU (weights not resident)
 using B_X1   = ConvCfg<bf16_t,  32,  64, 2, 80,  8, 2, 2, 5, 1, 32, 9>;     // L1 swizzled, 3 WGs/CU (168 registers)
 using B_X2   = ConvCfg<bf16_t,  64,  64, 1, 40,  8, 2, 2, 5, 1, 64, 9, 0, 0, true>;     // L2, two workgroups per CU
 using B_X3   = ConvCfg<bf16_t,  32,  32, 1, 80,  8, 4, 1, 5, 1, 32, 1>;     // L2 swizzled, 3 WGs/CU
-using B_X4   = ConvCfg<bf16_t, 128, 128, 1, 20,  8, 1, 4, 5, 1, 128, 9>;               // L3, padded image, two workgroups per CU
-using B_X5   = ConvCfg<bf16_t, 256, 256, 1, 10, 16, 1, 4, 5, 1, 128, 9, 3, 2, true>;    // L4 likewise
-using F_X4 = ConvCfg<float, 128, 128, 1, 20,  8, 1, 4, 5, 1, 128, 9>;
+using B_X4   = ConvCfg<bf16_t, 128, 256, 2, 20, 16, 1, 4, 5, 1, 64, 9>;    // L4A in 16-row tiles
+using B_X5   = ConvCfg<bf16_t, 256, 256, 1, 10, 16, 1, 4, 5, 1, 128, 9>;    // L4 in 16-row tiles
+using F_X4 = ConvCfg<float, 128, 256, 2, 20, 16, 1, 4, 5, 2, 32, 9>;
 using F_X5 = ConvCfg<float, 256, 256, 1, 10, 16, 1, 4, 5, 2, 128, 9>;
 using F_X0 = ConvCfg<float,  32,  32, 1, 80,  8, 4, 1, 5, 1, 32, 9>;
 using F_X1 = ConvCfg<float,  32,  64, 2, 80,  8, 2, 2, 5, 1, 16, 9>;
