@@ -11,53 +11,153 @@ __device__ inline float ld_elem(const void* x, int bf16, long idx) {
   return bf16 ? bf16_to_f32(reinterpret_cast<const uint16_t*>(x)[idx]) : reinterpret_cast<const float*>(x)[idx];
 }
 
-__global__ __launch_bounds__(256) void mean_std_kernel(const void* __restrict__ x, int x_bf16, long ld, int D, RowSpan rs,
-                                                       float* __restrict__ out) {
-  const int b = blockIdx.x, d = blockIdx.y * 256 + threadIdx.x;
-  if (d >= D) return;
+// Both pooling kernels: one workgroup per (utterance, 1024-column slab for bf16 / 512 for f32); a thread owns 16 B of
+// consecutive columns (8 bf16 / 4 f32) and every TG-th row, so a row leaves HBM/L2 as whole 16-B-per-lane loads and the
+// row loop is TG times shorter (one 2-B element per lane per row was latency-bound: 56 us for the 67 MB layer4 output);
+// the row groups meet in LDS in a fixed order.
+constexpr int POOL_TG = 4, POOL_CG = 64;   // 4 row groups x 64 column groups = 256 threads
+
+template <int VEC>
+__device__ inline void ld_vec(const void* x, long idx, float* v) {   // VEC = 8: bf16 elements, VEC = 4: f32 elements
+  const uint4 u = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(x) + idx * (16 / VEC));
+  const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+  if constexpr (VEC == 8) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { v[2 * q] = bf16_to_f32((uint16_t)(w[q] & 0xffff)); v[2 * q + 1] = bf16_to_f32((uint16_t)(w[q] >> 16)); }
+  } else {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = __builtin_bit_cast(float, w[q]);
+  }
+}
+
+// sums the POOL_TG row-group partials of `vals` (VEC per thread) in group order and broadcasts the totals
+template <int VEC>
+__device__ inline void rowgroup_sum(float (*red)[POOL_CG * 8], int tg, int cg, float* vals) {
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < VEC; ++q) red[tg][cg * VEC + q] = vals[q];
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < VEC; ++q) {
+    float t = 0.f;
+#pragma unroll
+    for (int g = 0; g < POOL_TG; ++g) t += red[g][cg * VEC + q];
+    vals[q] = t;
+  }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void mean_std_kernel(const void* __restrict__ x, long ld, int D, RowSpan rs, float* __restrict__ out) {
+  __shared__ float red[POOL_TG][POOL_CG * 8];
+  const int b = blockIdx.x, cg = threadIdx.x % POOL_CG, tg = threadIdx.x / POOL_CG;
+  const int d0 = (blockIdx.y * POOL_CG + cg) * VEC;
+  const bool live = d0 < D;
   const long r0 = rs.row0(b);
   const int n = rs.count(b);
-  float s = 0.f;
-  for (int t = 0; t < n; ++t) s += ld_elem(x, x_bf16, (r0 + t) * ld + d);
-  const float mean = s / (float)n;
-  float v = 0.f;
-  for (int t = 0; t < n; ++t) {
-    const float e = ld_elem(x, x_bf16, (r0 + t) * ld + d) - mean;
-    v = fmaf(e, e, v);
+  float s[VEC], v[VEC], e[VEC];
+#pragma unroll
+  for (int q = 0; q < VEC; ++q) { s[q] = 0.f; v[q] = 0.f; }
+  if (live)
+    for (int t = tg; t < n; t += POOL_TG) {
+      ld_vec<VEC>(x, (r0 + t) * ld + d0, e);
+#pragma unroll
+      for (int q = 0; q < VEC; ++q) s[q] += e[q];
+    }
+  rowgroup_sum<VEC>(red, tg, cg, s);
+  if (live)
+    for (int t = tg; t < n; t += POOL_TG) {
+      ld_vec<VEC>(x, (r0 + t) * ld + d0, e);
+#pragma unroll
+      for (int q = 0; q < VEC; ++q) { const float c = e[q] - s[q] / (float)n; v[q] = fmaf(c, c, v[q]); }
+    }
+  rowgroup_sum<VEC>(red, tg, cg, v);
+  if (live && tg == 0) {
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) {
+      out[(long)b * 2 * D + d0 + q] = s[q] / (float)n;
+      out[(long)b * 2 * D + D + d0 + q] = sqrtf(v[q] / (float)(n - 1));  // unbiased (torch.std default); n == 1 -> NaN as the reference
+    }
   }
-  out[(long)b * 2 * D + d] = mean;
-  out[(long)b * 2 * D + D + d] = sqrtf(v / (float)(n - 1));  // unbiased (torch.std default); n == 1 -> NaN as the reference
 }
 
 int launch_mean_std(const void* x, int x_bf16, long ld, int D, RowSpan rs, float* out, int B, hipStream_t s) {
-  hipLaunchKernelGGL(mean_std_kernel, dim3(B, cdiv(D, 256)), dim3(256), 0, s, x, x_bf16, ld, D, rs, out);
+  const int VEC = x_bf16 ? 8 : 4;
+  SK_CHECK(D % VEC == 0 && ld % VEC == 0, SK_EARG, "mean_std: D=%d, ld=%ld must be multiples of %d", D, ld, VEC);
+  const dim3 grid(B, cdiv(D, POOL_CG * VEC));
+  if (x_bf16) hipLaunchKernelGGL(mean_std_kernel<8>, grid, dim3(256), 0, s, x, ld, D, rs, out);
+  else hipLaunchKernelGGL(mean_std_kernel<4>, grid, dim3(256), 0, s, x, ld, D, rs, out);
   SK_HIP(hipGetLastError());
   return SK_OK;
 }
 
-__global__ __launch_bounds__(256) void att_stats_kernel(const void* __restrict__ x, int x_bf16, const float* __restrict__ e,
-                                                        long ld, int D, RowSpan rs, float* __restrict__ out) {
-  const int b = blockIdx.x, d = blockIdx.y * 256 + threadIdx.x;
-  if (d >= D) return;
+template <int VEC>
+__global__ __launch_bounds__(256) void att_stats_kernel(const void* __restrict__ x, const float* __restrict__ e, long ld, int D,
+                                                        RowSpan rs, float* __restrict__ out) {
+  __shared__ float red[POOL_TG][POOL_CG * 8];
+  const int b = blockIdx.x, cg = threadIdx.x % POOL_CG, tg = threadIdx.x / POOL_CG;
+  const int d0 = (blockIdx.y * POOL_CG + cg) * VEC;
+  const bool live = d0 < D;
   const long r0 = rs.row0(b);
   const int n = rs.count(b);
-  float mx = -INFINITY;
-  for (int t = 0; t < n; ++t) mx = fmaxf(mx, e[(r0 + t) * ld + d]);
-  float z = 0.f, s1 = 0.f, s2 = 0.f;
-  for (int t = 0; t < n; ++t) {
-    const float w = expf(e[(r0 + t) * ld + d] - mx);
-    const float xv = ld_elem(x, x_bf16, (r0 + t) * ld + d);
-    z += w;
-    s1 = fmaf(xv, w, s1);
-    s2 = fmaf(xv * xv, w, s2);
+  float mx[VEC], z[VEC], s1[VEC], s2[VEC], ev[VEC], xv[VEC];
+#pragma unroll
+  for (int q = 0; q < VEC; ++q) { mx[q] = -INFINITY; z[q] = 0.f; s1[q] = 0.f; s2[q] = 0.f; }
+  auto ld_e = [&](int t) {
+#pragma unroll
+    for (int q = 0; q < VEC; q += 4) {
+      const float4 f = *reinterpret_cast<const float4*>(e + (r0 + t) * ld + d0 + q);
+      ev[q] = f.x; ev[q + 1] = f.y; ev[q + 2] = f.z; ev[q + 3] = f.w;
+    }
+  };
+  if (live)
+    for (int t = tg; t < n; t += POOL_TG) {
+      ld_e(t);
+#pragma unroll
+      for (int q = 0; q < VEC; ++q) mx[q] = fmaxf(mx[q], ev[q]);
+    }
+  // max over the row groups
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < VEC; ++q) red[tg][cg * VEC + q] = mx[q];
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < VEC; ++q) {
+    float m = red[0][cg * VEC + q];
+#pragma unroll
+    for (int g = 1; g < POOL_TG; ++g) m = fmaxf(m, red[g][cg * VEC + q]);
+    mx[q] = m;
   }
-  const float mu = s1 / z;
-  out[(long)b * 2 * D + d] = mu;
-  out[(long)b * 2 * D + D + d] = sqrtf(fmaxf(s2 / z - mu * mu, 1e-9f));
+  if (live)
+    for (int t = tg; t < n; t += POOL_TG) {
+      ld_e(t);
+      ld_vec<VEC>(x, (r0 + t) * ld + d0, xv);
+#pragma unroll
+      for (int q = 0; q < VEC; ++q) {
+        const float w = expf(ev[q] - mx[q]);
+        z[q] += w;
+        s1[q] = fmaf(xv[q], w, s1[q]);
+        s2[q] = fmaf(xv[q] * xv[q], w, s2[q]);
+      }
+    }
+  rowgroup_sum<VEC>(red, tg, cg, z);
+  rowgroup_sum<VEC>(red, tg, cg, s1);
+  rowgroup_sum<VEC>(red, tg, cg, s2);
+  if (live && tg == 0) {
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) {
+      const float mu = s1[q] / z[q];
+      out[(long)b * 2 * D + d0 + q] = mu;
+      out[(long)b * 2 * D + D + d0 + q] = sqrtf(fmaxf(s2[q] / z[q] - mu * mu, 1e-9f));
+    }
+  }
 }
 
 int launch_att_stats(const void* x, int x_bf16, const float* e, long ld, int D, RowSpan rs, float* out, int B, hipStream_t s) {
-  hipLaunchKernelGGL(att_stats_kernel, dim3(B, cdiv(D, 256)), dim3(256), 0, s, x, x_bf16, e, ld, D, rs, out);
+  const int VEC = x_bf16 ? 8 : 4;
+  SK_CHECK(D % VEC == 0 && ld % VEC == 0, SK_EARG, "att_stats: D=%d, ld=%ld must be multiples of %d", D, ld, VEC);
+  const dim3 grid(B, cdiv(D, POOL_CG * VEC));
+  if (x_bf16) hipLaunchKernelGGL(att_stats_kernel<8>, grid, dim3(256), 0, s, x, e, ld, D, rs, out);
+  else hipLaunchKernelGGL(att_stats_kernel<4>, grid, dim3(256), 0, s, x, e, ld, D, rs, out);
   SK_HIP(hipGetLastError());
   return SK_OK;
 }
