@@ -7,7 +7,8 @@
 // split.  512 = 8^3: three Stockham (autosort) radix-8 passes, every lane owning one 8-point butterfly
 // per pass; passes exchange data through a 4.6-KB per-wave LDS buffer (index padded by i>>3 so the
 // stride-8 scatter of pass 1 is bank-conflict free); no workgroup barrier is ever needed.
-// Output: |X[k]|^2, k = 0..512 (+3 zero pad columns), f32, row stride 516 -- the mel projection stays a GEMM.
+// Output: |X[k]|^2, k = 0..512 (+3 zero pad columns), f32, row stride 516 -- or, with the mel projection fused, the
+// log-mel row itself (the power spectrum then never leaves LDS: 211 MB less to write and read back at B=256 x 4 s).
 #include "kernels.h"
 
 namespace sk {
@@ -39,6 +40,7 @@ constexpr int FFT_BUF = 512 + 64;  // padded complex slots per wave
 
 __global__ __launch_bounds__(FFT_WAVES * 64) void stft_power_fft_kernel(FftArgs a) {
   __shared__ __attribute__((aligned(16))) cf lds[FFT_WAVES * FFT_BUF];
+  __shared__ float pws[FFT_WAVES][520];   // fused mel projection: the frame's power spectrum stays in LDS
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int m = blockIdx.x * FFT_WAVES + wave;
   if (m >= a.M) return;
@@ -46,9 +48,10 @@ __global__ __launch_bounds__(FFT_WAVES * 64) void stft_power_fft_kernel(FftArgs 
   int b, t;
   if (a.row_b) { b = a.row_b[m]; t = a.row_t[m]; } else { b = m / a.t_max; t = m % a.t_max; }
   const int L = a.nsamples ? a.nsamples[b] : a.nsamples_uniform;
-  float* prow = a.P + (long)m * a.ldp;
-  if (t > L / a.hop) {  // frame beyond this utterance: keep the row defined
-    for (int k = lane; k < a.ldp; k += 64) prow[k] = 0.f;
+  float* prow = a.mel_w ? nullptr : a.P + (long)m * a.ldp;
+  if (t > L / a.hop) {  // frame beyond this utterance: keep the row defined (zero power)
+    if (a.mel_w) { for (int j = lane; j < a.n_mels; j += 64) a.logmel[(long)m * a.ldl + j] = logf(1e-6f); }
+    else { for (int k = lane; k < a.ldp; k += 64) prow[k] = 0.f; }
     return;
   }
   const float* w = a.wav + (long)b * a.wav_ld;
@@ -103,12 +106,21 @@ __global__ __launch_bounds__(FFT_WAVES * 64) void stft_power_fft_kernel(FftArgs 
       const float re = 0.5f * (s.x + wd.y), im = 0.5f * (s.y - wd.x);  // s/2 - i*wd/2
       pw = re * re + im * im;
     }
-    prow[k] = pw;
+    if (a.mel_w) pws[wave][k] = pw;
+    else prow[k] = pw;
+  }
+  if (a.mel_w) {  // each lane finishes filters lane and lane + 64: a dot product over the filter's own run of bins
+    for (int j = lane; j < a.n_mels; j += 64) {
+      const int k0 = a.mel_start[j], n = a.mel_len[j];
+      float acc = 0.f;
+      for (int i = 0; i < n; ++i) acc = fmaf(a.mel_w[i * a.n_mels + j], pws[wave][k0 + i], acc);
+      a.logmel[(long)m * a.ldl + j] = logf(acc + 1e-6f);
+    }
   }
 }
 
 int launch_stft_power_fft(const FftArgs& a, hipStream_t s) {
-  SK_CHECK(a.M > 0 && a.ldp >= 513, SK_EARG, "stft_power_fft: bad arguments");
+  SK_CHECK(a.M > 0 && (a.mel_w ? (a.ldp >= 513 && a.ldp <= 520 && a.logmel && a.mel_start && a.mel_len && a.n_mels > 0) : a.ldp >= 513), SK_EARG, "stft_power_fft: bad arguments");
   hipLaunchKernelGGL(stft_power_fft_kernel, dim3(cdiv(a.M, FFT_WAVES)), dim3(FFT_WAVES * 64), 0, s, a);
   SK_HIP(hipGetLastError());
   return SK_OK;

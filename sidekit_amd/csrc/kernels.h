@@ -127,6 +127,10 @@ struct FftArgs {
   int M, t_max, hop;
   const int* row_b; const int* row_t;          // optional ragged row map
   float preemph;
+  // fused mel projection (mel_w != nullptr): instead of P the kernel writes logmel[m][j] = log(sum_k fb[k][j] P[k] + 1e-6);
+  // every filter is a short run of bins (triangles: <= 31 of 513), stored compacted as mel_w[i][j] = fb[mel_start[j] + i][j]
+  const float* mel_w; const int* mel_start; const int* mel_len; int n_mels;
+  float* logmel; long ldl;
 };
 int launch_stft_power_fft(const FftArgs& a, hipStream_t s);
 

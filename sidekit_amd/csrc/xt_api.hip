@@ -71,6 +71,7 @@ using namespace sk;
 
 struct xt_handle {
   bool shortcut_tensor = getenv("SIDEKIT_AMD_SHORTCUT_TENSOR") != nullptr;   // A/B switch, see half_from_feats
+  bool mel_gemm = getenv("SIDEKIT_AMD_MEL_GEMM") != nullptr;                 // A/B switch: mel projection as a separate GEMM
   xt_config cfg;
   int device = 0;
   bool finalized = false;
@@ -83,6 +84,7 @@ struct xt_handle {
   float* d_window = nullptr;
   float* d_basis = nullptr;  // [2*nbp][win]
   float* d_fbT = nullptr;    // [n_mels][nbp]
+  float* d_mel_w = nullptr; int* d_mel_start = nullptr; int* d_mel_len = nullptr; bool mel_fused = false;   // compacted bank (frontend_fft.hip)
   float* d_dctT = nullptr;   // [n_out][n_mels] (MFCC)
   float* d_tw512 = nullptr;  // FFT twiddles (log-mel front-end)
   float* d_tw1024 = nullptr;
@@ -268,6 +270,26 @@ static int build_frontend(xt_handle* h) {
   for (int j = 0; j < nb; ++j)
     for (int m = 0; m < f.n_mels; ++m) fbT[(size_t)m * h->nbp + j] = fb[(size_t)j * f.n_mels + m];
   SK_TRY(upload_f(h, fbT, &h->d_fbT));
+  if (mel) {  // compacted filters for the projection fused into the FFT kernel: filter j = bins [start, start + len)
+    std::vector<int> st(f.n_mels, 0), ln(f.n_mels, 0);
+    int maxlen = 0;
+    for (int m = 0; m < f.n_mels; ++m) {
+      int lo = nb, hi = -1;
+      for (int j = 0; j < nb; ++j)
+        if (fb[(size_t)j * f.n_mels + m] != 0.f) { lo = j < lo ? j : lo; hi = j; }
+      if (hi >= lo) { st[m] = lo; ln[m] = hi - lo + 1; }
+      maxlen = ln[m] > maxlen ? ln[m] : maxlen;
+    }
+    h->mel_fused = maxlen > 0 && maxlen <= 64;   // a dense or very wide bank stays on the GEMM path
+    if (h->mel_fused) {
+      std::vector<float> wc((size_t)maxlen * f.n_mels, 0.f);
+      for (int m = 0; m < f.n_mels; ++m)
+        for (int i = 0; i < ln[m]; ++i) wc[(size_t)i * f.n_mels + m] = fb[(size_t)(st[m] + i) * f.n_mels + m];
+      SK_TRY(upload_f(h, wc, &h->d_mel_w));
+      SK_TRY(upload(h, st.data(), st.size() * sizeof(int), (void**)&h->d_mel_start));
+      SK_TRY(upload(h, ln.data(), ln.size() * sizeof(int), (void**)&h->d_mel_len));
+    }
+  }
   if (mel) {  // twiddles of the 1024-point real FFT (frontend_fft.hip), rounded once from double
     std::vector<float> t512(2 * 512), t1024(2 * 513);
     for (int m = 0; m < 512; ++m) { t512[2 * m] = (float)cos(2.0 * M_PI * m / 512.0); t512[2 * m + 1] = (float)(-sin(2.0 * M_PI * m / 512.0)); }
@@ -508,6 +530,15 @@ static int frontend_rows(xt_handle* h, const float* d_wav, int64_t wav_ld, const
     fa.tw512 = h->d_tw512; fa.tw1024 = h->d_tw1024; fa.P = (float*)h->ws_S.p; fa.ldp = h->nbp; fa.M = M; fa.t_max = m.T; fa.hop = f.hop;
     fa.row_b = m.d_row_b; fa.row_t = m.d_row_t; fa.preemph = 0.97f;
     SK_CHECK((size_t)M * h->nbp * 4 <= h->ws_S.bytes, SK_EWORKSPACE, "spectrum workspace too small (xt_reserve)");
+    fa.mel_w = nullptr; fa.mel_start = nullptr; fa.mel_len = nullptr; fa.n_mels = 0; fa.logmel = nullptr; fa.ldl = 0;
+    if (h->mel_fused && !h->mel_gemm) {  // power spectrum stays in LDS, the kernel writes log-mel rows
+      fa.mel_w = h->d_mel_w; fa.mel_start = h->d_mel_start; fa.mel_len = h->d_mel_len; fa.n_mels = f.n_mels;
+      fa.logmel = d_feat_rows; fa.ldl = f.n_mels;
+      { ProfScope ps(h, XT_PROF_FRONTEND, st); SK_TRY(launch_stft_power_fft(fa, st)); }
+      RowSpan rs{m.d_offsets, m.T, m.lens, 0, 0};
+      { ProfScope ps(h, XT_PROF_FRONTEND, st); SK_TRY(launch_cmvn(d_feat_rows, f.n_out, f.n_out, rs, 1e-5f, m.B, st)); }
+      return SK_OK;
+    }
     { ProfScope ps(h, XT_PROF_FRONTEND, st); SK_TRY(launch_stft_power_fft(fa, st)); }
     // 2) power x mel filterbank, log(. + 1e-6)
     p.a_mode = A_PLAIN; p.A = h->ws_S.p; p.lda = h->nbp; p.a_rows = M;
