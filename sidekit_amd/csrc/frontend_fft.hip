@@ -110,10 +110,17 @@ __global__ __launch_bounds__(FFT_WAVES * 64) void stft_power_fft_kernel(FftArgs 
     else prow[k] = pw;
   }
   if (a.mel_w) {  // each lane finishes filters lane and lane + 64: a dot product over the filter's own run of bins
+    for (int k = 513 + lane; k < 520; k += 64) pws[wave][k] = 0.f;   // the 8-wide steps below may read past bin 512
     for (int j = lane; j < a.n_mels; j += 64) {
       const int k0 = a.mel_start[j], n = a.mel_len[j];
       float acc = 0.f;
-      for (int i = 0; i < n; ++i) acc = fmaf(a.mel_w[i * a.n_mels + j], pws[wave][k0 + i], acc);
+      for (int i = 0; i < n; i += 8) {   // eight taps per step, all loads in flight together (mel_w is zero-padded to a multiple of 8 rows)
+        float wv[8], pv[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { wv[q] = a.mel_w[(i + q) * a.n_mels + j]; pv[q] = pws[wave][k0 + i + q]; }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc = fmaf(wv[q], pv[q], acc);
+      }
       a.logmel[(long)m * a.ldl + j] = logf(acc + 1e-6f);
     }
   }

@@ -282,7 +282,7 @@ static int build_frontend(xt_handle* h) {
     }
     h->mel_fused = maxlen > 0 && maxlen <= 64;   // a dense or very wide bank stays on the GEMM path
     if (h->mel_fused) {
-      std::vector<float> wc((size_t)maxlen * f.n_mels, 0.f);
+      std::vector<float> wc((size_t)((maxlen + 7) / 8 * 8) * f.n_mels, 0.f);   // zero rows up to a multiple of 8 taps
       for (int m = 0; m < f.n_mels; ++m)
         for (int i = 0; i < ln[m]; ++i) wc[(size_t)i * f.n_mels + m] = fb[(size_t)(st[m] + i) * f.n_mels + m];
       SK_TRY(upload_f(h, wc, &h->d_mel_w));
