@@ -420,3 +420,103 @@ def extract_embeddings(idmap_name, model_filename, data_root_name, device, batch
     embeddings.stop = numpy.array(stops).squeeze()
     embeddings.stat0 = numpy.ones((embeddings.modelset.shape[0], 1))
     return embeddings
+
+
+def _load_model(model_filename):
+    """A checkpoint file name -> Xtractor (``extract_embeddings`` :1822-1829); an Xtractor is returned as is."""
+    if isinstance(model_filename, str):
+        checkpoint = torch.load(model_filename, map_location="cpu", weights_only=False)
+        model_opts = checkpoint["model_archi"]
+        model = Xtractor(checkpoint["speaker_number"], model_archi=model_opts["model_type"], loss=model_opts["loss"]["type"],
+                         embedding_size=256)
+        model.load_state_dict(checkpoint["model_state_dict"])
+        return model
+    return model_filename
+
+
+def extract_embeddings_per_speaker(idmap_name, model_filename, data_root_name, device, file_extension="wav", transform_pipeline={},
+                                   sample_rate=16000, mixed_precision=False, num_thread=1, dither=10e-6):
+    """``sidekit.nnet.xvector.extract_embeddings_per_speaker`` (``sidekit/nnet/xvector.py:1919-1999``): ONE x-vector per
+    speaker from the concatenation of all of the speaker's segments (``IdMapSetPerSpeaker``, ``xsets.py:483-590``,
+    ``min_duration`` 1 s), truncated to 20 000 000 samples, always ``norm_embedding=True``.
+
+    Same arguments plus ``dither``: the reference adds ``10e-6 * randn`` to every segment before concatenating
+    (``xsets.py:572``); the same is done here from torch's global generator, ``dither=0`` makes the call deterministic.
+    Speakers come out in ``numpy.unique`` order; ``start`` / ``stop`` are ``None`` per row (the reference leaves them as
+    empty object arrays).  A whole-file segment is read from its OWN file (the reference indexes ``rightids`` by the
+    speaker index there, ``xsets.py:558``, which reads the wrong file whenever ids are not aligned)."""
+    from ..bosaris import IdMap
+    from ..statserver import StatServer
+    if transform_pipeline:
+        raise NotImplementedError("augmentation pipelines are training-time (out of scope)")
+    model = _load_model(model_filename)
+    idmap = idmap_name if isinstance(idmap_name, IdMap) else IdMap(idmap_name)
+    model.eval()
+    model.to(device)
+    prev_dtype = model.compute_dtype
+    if mixed_precision and model.model_archi == "halfresnet34":
+        model.compute_dtype = "bf16"
+    speakers = numpy.unique(idmap.leftids)
+    stat1 = numpy.ones((speakers.shape[0], model.embedding_size))
+    try:
+        with torch.no_grad():
+            for idx, spk in enumerate(speakers):
+                parts = []
+                for sid, seg_id, seg_start, seg_stop in zip(idmap.leftids, idmap.rightids, idmap.start, idmap.stop):
+                    if sid != spk:
+                        continue
+                    speech, _, _ = _load_segment(data_root_name, seg_id, file_extension, seg_start, seg_stop, sample_rate, 1.)
+                    if dither:
+                        speech = speech + dither * torch.randn(speech.shape)
+                    parts.append(speech)
+                data = torch.cat(parts)[:20000000].unsqueeze(0)
+                out = model(data.to(model.device), is_eval=True, norm_embedding=True)
+                stat1[idx, :] = (out[1] if isinstance(out, tuple) else out).detach().cpu().numpy()
+    finally:
+        model.compute_dtype = prev_dtype
+    embeddings = StatServer()
+    embeddings.modelset = speakers
+    embeddings.segset = speakers
+    embeddings.start = numpy.empty(speakers.shape[0], "|O")
+    embeddings.stop = numpy.empty(speakers.shape[0], "|O")
+    embeddings.stat0 = numpy.ones((speakers.shape[0], 1))
+    embeddings.stat1 = stat1
+    return embeddings
+
+
+def test_metrics(model, device, model_opts, data_opts, train_opts, as_norm=True):
+    """``sidekit.nnet.xvector.test_metrics`` (``sidekit/nnet/xvector.py:212-271``): x-vectors of the test IdMap, all-vs-all
+    cosine, the trials of the Ndx, EER from ``rocch`` / ``rocch2eer``; with ``as_norm`` also the EER of the adaptive
+    s-normalised scores (cohort = rows of ``after_speaker_embedding.weight``), returned as ``(eer, norm_eer)``.
+
+    ``data_opts["test"]["ndx"]`` / ``["key"]`` may be ``Ndx`` / ``Key`` objects or file names (HDF5 needs h5py, text
+    files go through ``read_txt``).  The N x N cosine matrix and the normalisation run on the GPU."""
+    from ..bosaris import Key, Ndx
+    from ..bosaris.detplot import rocch, rocch2eer
+    from ..iv_scoring import cosine_matrix
+    from ..score_normalization import asnorm
+    model = _load_model(model)
+    xv_stat = extract_embeddings(idmap_name=data_opts["test"]["idmap"], model_filename=model,
+                                 data_root_name=data_opts["test"]["data_path"], device=device, transform_pipeline={},
+                                 num_thread=train_opts.get("num_cpu", 1), mixed_precision=train_opts.get("mixed_precision", False),
+                                 batch_size=train_opts.get("batch_size", 1))
+
+    def load(cls, x):
+        if isinstance(x, cls):
+            return x
+        return cls.read_txt(x) if str(x).endswith(".txt") else cls(x)
+
+    ndx, key = load(Ndx, data_opts["test"]["ndx"]), load(Key, data_opts["test"]["key"])
+    tsr = torch.nn.functional.normalize(torch.as_tensor(xv_stat.stat1, dtype=torch.float32), dim=1)
+    scores = cosine_matrix(tsr, tsr)[ndx.trialmask]
+    tar, non = key.tar[ndx.trialmask], key.non[ndx.trialmask]
+    pmiss, pfa = rocch(scores[tar], scores[non])
+    if not as_norm:
+        return rocch2eer(pmiss, pfa)
+    cohort = torch.as_tensor(model.state_dict()["after_speaker_embedding.weight"], dtype=torch.float32)
+    s_scores = asnorm(tsr, torch.nn.functional.normalize(cohort, dim=1), ndx)[ndx.trialmask]
+    norm_pmiss, norm_pfa = rocch(s_scores[tar], s_scores[non])
+    return rocch2eer(pmiss, pfa), rocch2eer(norm_pmiss, norm_pfa)
+
+
+test_metrics.__test__ = False   # a library function with the reference's name, not a pytest case

@@ -123,3 +123,76 @@ def test_extract_embeddings_statserver(gpu, tmp_path):
     assert model.compute_dtype is None
     cos = float((mp.stat1[0] * st.stat1[0]).sum())
     assert 0.999 < cos < 1.0 - 1e-9
+
+
+def test_extract_embeddings_per_speaker(gpu, tmp_path):
+    """xvector.py:1919-1999 / xsets.py:483-590: one x-vector per speaker from the concatenation of the speaker's segments."""
+    from sidekit_amd.bosaris import IdMap
+    from sidekit_amd.nnet import Xtractor, extract_embeddings_per_speaker
+    rs = numpy.random.RandomState(6)
+    sd = seeded_state_dict("halfresnet34", 16, seed=79)
+    model = Xtractor(16, "halfresnet34", "aam", seed=0)
+    model.load_state_dict(sd)
+    waves = {}
+    for name, n in (("a", 40000), ("b", 33000), ("c", 50001), ("d", 20000)):
+        x = (0.1 * rs.randn(n) * 32768).clip(-32768, 32767).astype(numpy.int16)
+        scipy.io.wavfile.write(tmp_path / f"{name}.wav", 16000, x)
+        waves[name] = torch.from_numpy(x.astype(numpy.float32) / 32768.0)
+    im = IdMap()   # spk2 first in the file, spk1's segments interleaved; one start/stop segment shorter than 1 s (widened)
+    im.set(numpy.array(["spk2", "spk1", "spk2", "spk1"], dtype=object), numpy.array(["c", "a", "d", "b"], dtype=object),
+           numpy.array([None, None, 20, None], dtype=object), numpy.array([None, None, 70, None], dtype=object))
+    st = extract_embeddings_per_speaker(im, model, str(tmp_path), "cuda", dither=0)
+    assert st.validate() and list(st.modelset) == ["spk1", "spk2"] and list(st.segset) == ["spk1", "spk2"]
+    assert st.stat1.shape == (2, 256) and st.stat0.shape == (2, 1) and st.start[0] is None
+    mid = 3200 + 8000 // 2                                  # 0.2 s .. 0.7 s of d: 0.5 s < 1 s -> 1 s around its middle
+    s0 = int(max(0, mid - 8000))
+    cat = [torch.cat([waves["a"], waves["b"]]), torch.cat([waves["c"], waves["d"][s0:s0 + 16000]])]
+    with torch.no_grad():
+        _, ref = oxv.forward_ragged(cat, sd)
+    for i in range(2):
+        assert numpy.linalg.norm(st.stat1[i] - ref[i].numpy()) / numpy.linalg.norm(ref[i].numpy()) < 1e-4
+    torch.manual_seed(0)
+    dith = extract_embeddings_per_speaker(im, model, str(tmp_path), "cuda")          # the reference's 1e-5 dither
+    cos = (dith.stat1 * st.stat1).sum(axis=1)
+    assert (cos > 0.9999).all() and not numpy.array_equal(dith.stat1, st.stat1)
+
+
+def test_test_metrics(gpu, tmp_path):
+    """xvector.py:212-271: IdMap -> x-vectors -> all-vs-all cosine -> Ndx trials -> EER, and the as-norm EER."""
+    from oracle import scoring as osc
+    from sidekit_amd.bosaris import IdMap, Key, Ndx
+    from sidekit_amd.nnet import Xtractor, test_metrics
+    rs = numpy.random.RandomState(7)
+    n_spk = 256                                             # the as-norm cohort = the 256 rows of the cosine head (top-200 of them)
+    sd = seeded_state_dict("halfresnet34", n_spk, seed=80)
+    model = Xtractor(n_spk, "halfresnet34", "aam", seed=0)
+    model.load_state_dict(sd)
+    names, spk, waves = [], [], []
+    for s in range(3):
+        base = rs.randn(30000)
+        for u in range(3):
+            x = ((0.08 * base[:24000 + 2000 * u] + 0.03 * rs.randn(24000 + 2000 * u)) * 32768).clip(-32768, 32767).astype(numpy.int16)
+            name = f"s{s}u{u}"
+            scipy.io.wavfile.write(tmp_path / f"{name}.wav", 16000, x)
+            names.append(name); spk.append(f"s{s}"); waves.append(torch.from_numpy(x.astype(numpy.float32) / 32768.0))
+    im = IdMap()
+    im.set(numpy.array(spk, dtype=object), numpy.array(names, dtype=object))
+    n = len(names)
+    mask = ~numpy.eye(n, dtype=bool)
+    tar = numpy.array([[a == b for b in spk] for a in spk]) & mask
+    ndx = Ndx(models=numpy.array(names, dtype=object), testsegs=numpy.array(names, dtype=object))
+    ndx.trialmask = mask
+    key = Key()
+    key.modelset = key.segset = numpy.array(names, dtype=object)
+    key.tar, key.non = tar, mask & ~tar
+    opts = {"test": {"idmap": im, "data_path": str(tmp_path), "ndx": ndx, "key": key}}
+    eer, norm_eer = test_metrics(model, "cuda", {}, opts, {"num_cpu": 1, "mixed_precision": False, "batch_size": 4})
+    with torch.no_grad():
+        _, ref = oxv.forward_ragged(waves, sd)
+    e = torch.nn.functional.normalize(ref, dim=1)
+    sc = (e @ e.T).numpy()
+    assert abs(eer - osc.eer(sc[tar], sc[mask & ~tar])) < 1e-9
+    cohort = torch.nn.functional.normalize(sd["after_speaker_embedding.weight"], dim=1)
+    sn = osc.asnorm(e.numpy(), cohort.numpy(), topk=200)
+    assert abs(norm_eer - osc.eer(sn[tar], sn[mask & ~tar])) < 1e-9
+    assert test_metrics(model, "cuda", {}, opts, {"num_cpu": 1, "mixed_precision": False}, as_norm=False) == eer
