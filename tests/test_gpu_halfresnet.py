@@ -179,3 +179,28 @@ def test_row_tile_boundaries(model):
     _, emb = model(wav.cuda(), is_eval=True, lengths=lens)
     for i, n in enumerate(lens):
         assert rel(emb[i], ref[i]) < TOL, (i, n, 1 + n // 160)
+
+
+def test_bf16_row_tile_boundaries_and_per_utterance(model):
+    """The bf16 path has its own tilings (17-row layer4 tiles, three workgroups per CU, persistent layer1 workgroups, the
+    in-place first-block shortcut): frame counts around every row-tile edge, batched (ragged, garbage in the padding) vs
+    each utterance alone -- bit for bit -- and against the fp32 path."""
+    frames = [17 * 8, 17 * 8 + 1, 34 * 8, 34 * 8 + 1, 51 * 8 - 7, 51 * 8 + 1, 65, 129, 401, 64]
+    lens = [(t - 1) * 160 + 11 for t in frames]
+    torch.manual_seed(13)
+    wav = 0.1 * torch.randn(len(lens), max(lens))
+    padded = wav.clone()
+    for i, n in enumerate(lens):
+        padded[i, n:] = -3.0
+    _, e32 = model(padded.cuda(), is_eval=True, lengths=lens)
+    model.compute_dtype = "bf16"
+    try:
+        _, e16 = model(padded.cuda(), is_eval=True, lengths=lens)
+        assert bool(torch.isfinite(e16).all())
+        cos = torch.nn.functional.cosine_similarity(e16, e32)
+        assert float(cos.min()) > 0.999, cos
+        for i in (0, 1, 3, 5, 8):
+            _, one = model(wav[i, :lens[i]].cuda(), is_eval=True)
+            assert torch.equal(one[0], e16[i]), (i, frames[i])
+    finally:
+        model.compute_dtype = "fp32"
