@@ -610,19 +610,16 @@ using B_L4A  = ConvCfg<bf16_t, 128, 256, 2, 20, 17, 1, 4, 6, 1, 64, 9>;    // 17
 using B_L4S  = ConvCfg<bf16_t, 128, 256, 2, 20, 16, 1, 4, 5, 1, 64, 1>;
 using B_L4   = ConvCfg<bf16_t, 256, 256, 1, 10, 17, 1, 4, 6, 1, 128, 9, 2>;   // 170 of 192 M-tile slots used; NT = 128: two workgroups per CU
 
-// tuning candidates (sk_bench_conv shapes 11..): smaller halo tiles, more workgroups per CU
-using B_X0   = ConvCfg<bf16_t,  32,  32, 1, 80,  8, 4, 1, 5, 1, 32, 9, 3, 6, true>;     // L1 at three workgroups per CU (weights not resident)
-using B_X1   = ConvCfg<bf16_t,  32,  64, 2, 80,  8, 2, 2, 5, 1, 32, 9>;     // L1 swizzled, 3 WGs/CU (168 registers)
-using B_X2   = ConvCfg<bf16_t,  64,  64, 1, 40,  8, 2, 2, 5, 1, 64, 9, 0, 0, true>;     // L2, two workgroups per CU
-using B_X3   = ConvCfg<bf16_t,  32,  32, 1, 80,  8, 4, 1, 5, 1, 32, 1>;     // L2 swizzled, 3 WGs/CU
-using B_X4   = ConvCfg<bf16_t, 128, 256, 2, 20, 16, 1, 4, 5, 1, 64, 9>;    // L4A in 16-row tiles
-using B_X5   = ConvCfg<bf16_t, 256, 256, 1, 10, 16, 1, 4, 5, 1, 128, 9>;    // L4 in 16-row tiles
-using F_X4 = ConvCfg<float, 128, 256, 2, 20, 16, 1, 4, 5, 2, 32, 9>;
-using F_X5 = ConvCfg<float, 256, 256, 1, 10, 16, 1, 4, 5, 2, 128, 9>;
+// tuning alternatives kept for A/B runs inside one process (sk_bench_conv shapes 11..14, scripts/conv_bench.py): each is
+// the configuration the product shape above it replaced, with the measured difference at B = 256
+using B_X0   = ConvCfg<bf16_t,  32,  32, 1, 80,  8, 4, 1, 5, 1, 32, 9, 3, 6, true>;     // L1 at three WGs/CU, weights not resident: statistics form 283 vs 232 us
+using B_X1   = ConvCfg<bf16_t,  64,  64, 1, 40,  8, 2, 2, 5, 1, 64, 9, 0, 0, true>;     // L2 at two WGs/CU: 165 vs 158 us
+using B_X2   = ConvCfg<bf16_t, 128, 128, 1, 20,  8, 1, 4, 5, 1, 128, 9>;                // L3, padded image, two WGs/CU: 127 vs 116 us
+using B_X3   = ConvCfg<bf16_t, 256, 256, 1, 10, 16, 1, 4, 5, 1, 128, 9>;                // L4 in 16-row tiles: 168 vs 137 us
 using F_X0 = ConvCfg<float,  32,  32, 1, 80,  8, 4, 1, 5, 1, 32, 9>;
-using F_X1 = ConvCfg<float,  32,  64, 2, 80,  8, 2, 2, 5, 1, 16, 9>;
-using F_X2 = ConvCfg<float,  64,  64, 1, 40,  8, 2, 2, 5, 1, 64, 9>;
-using F_X3 = ConvCfg<float,  32,  32, 1, 80,  8, 4, 1, 5, 1, 32, 1>;
+using F_X1 = ConvCfg<float,  64,  64, 1, 40,  8, 2, 2, 5, 1, 64, 9>;
+using F_X2 = ConvCfg<float, 128, 128, 1, 20,  8, 1, 4, 5, 1, 128, 9>;
+using F_X3 = ConvCfg<float, 256, 256, 1, 10, 16, 1, 4, 5, 2, 128, 9>;
 
 using F_L1   = ConvCfg<float,  32,  32, 1, 80,  8, 4, 1, 5, 1, 32, 9, 0, 0, true>;
 using F_L1S  = ConvCfg<float,  32,  32, 1, 80,  8, 4, 1, 5, 1, 32, 1, 0, 0, true>;
@@ -645,7 +642,7 @@ static void fill_geom(ConvGeom& g) {
 #define SK_CONV_CASES(X) \
   X(CONV_L1, L1) X(CONV_L1S, L1S) X(CONV_L2A, L2A) X(CONV_L2S, L2S) X(CONV_L2, L2) X(CONV_L3A, L3A) \
   X(CONV_L3S, L3S) X(CONV_L3, L3) X(CONV_L4A, L4A) X(CONV_L4S, L4S) X(CONV_L4, L4) \
-  X(11, X0) X(12, X1) X(13, X2) X(14, X3) X(15, X4) X(16, X5)
+  X(11, X0) X(12, X1) X(13, X2) X(14, X3)
 
 int conv_geom(int shape, int dtype, ConvGeom* g) {
   switch (shape) {
