@@ -86,3 +86,21 @@ def test_config4_tdnn_512_variable_length(gpu):
     with torch.no_grad():
         _, ref = oxv.forward_ragged([wav[i, :lens[i]].cpu() for i in idx], m.state_dict(), arch="xvector")
     assert rel(emb[idx], ref) < 1e-4
+
+
+def test_long_utterance_45s(model):
+    """Per-speaker concatenations (xvector.py:1919-1999) and sliding-window sources are long single utterances: 45 s =
+    4501 frames (563 layer1 row tiles, T' = 563 pooled frames) against the oracle in fp32, and bf16 next to it."""
+    g = torch.Generator(device="cuda").manual_seed(3)
+    wav = 0.1 * torch.randn(1, 45 * 16000, device="cuda", generator=g)
+    model.compute_dtype = "fp32"
+    _, e32 = model(wav, is_eval=True)
+    with torch.no_grad():
+        _, ref = oxv.halfresnet34_forward(wav.cpu(), model.state_dict())
+    assert rel(e32, ref) < 1e-4
+    model.compute_dtype = "bf16"
+    try:
+        _, e16 = model(wav, is_eval=True)
+    finally:
+        model.compute_dtype = "fp32"
+    assert float(torch.nn.functional.cosine_similarity(e16, e32).min()) > 0.999
