@@ -7,7 +7,8 @@ namespace sk {
 
 // ---- stem: relu(bn(conv3x3(1->32, pad 1))) on the logical (B,1,H=T,W=80) image -----------------
 // One workgroup = TT time rows x 80 freqs; the (TT+2) x 82 input patch goes through LDS, every
-// thread produces one position x 32 channels (288 FMAs, weights as SGPR operands) and writes 64 B (bf16) / 128 B (f32).
+// thread produces one position x 32 channels (288 FMAs as 144 packed-f32 FMAs, weights as SGPR operands) and writes
+// 64 B (bf16) / 128 B (f32).
 constexpr int STEM_TT = 16;
 constexpr int STEM_W = 80;
 
@@ -17,6 +18,7 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ fea
                                                    const float* __restrict__ shift, unsigned char* __restrict__ out,
                                                    Lens lens, int T) {
   __shared__ float patch[(STEM_TT + 2) * (STEM_W + 2)];
+  __shared__ __attribute__((aligned(16))) unsigned char stage[256 * (32 * EB + 16)];
   const int tid = threadIdx.x;
   const int tiles = (T + STEM_TT - 1) / STEM_TT;
   const int b = blockIdx.x / tiles, t0 = (blockIdx.x % tiles) * STEM_TT;
@@ -30,32 +32,53 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ fea
     patch[i] = v;
   }
   __syncthreads();
-  for (int p = tid; p < STEM_TT * STEM_W; p += 256) {
+  // 1280 positions = 5 rounds of 256; a round's outputs are 256 consecutive NHWC positions = one contiguous 16 / 32 KB
+  // run, staged through LDS so that every store instruction writes whole 1-KB lines (a thread storing its own 64 B at a
+  // 64-B lane stride ran at 2.9 TB/s)
+  constexpr int PB = 32 * EB, PS = PB + 16;   // bytes per position, padded LDS stride
+  for (int p0 = 0; p0 < STEM_TT * STEM_W; p0 += 256) {
+    const int p = p0 + tid;
     const int tl = p / STEM_W, f = p % STEM_W;
     const int t = t0 + tl;
-    if (t >= tb) continue;
-    float x[9];
+    if (t < tb) {
+      float x[9];
 #pragma unroll
-    for (int q = 0; q < 9; ++q) x[q] = patch[(tl + q / 3) * (STEM_W + 2) + f + q % 3];
-    unsigned char* op = out + (((size_t)b * T + t) * STEM_W + f) * 32 * EB;
+      for (int q = 0; q < 9; ++q) x[q] = patch[(tl + q / 3) * (STEM_W + 2) + f + q % 3];
+      unsigned char* lp = stage + tid * PS;
 #pragma unroll
-    for (int c0 = 0; c0 < 32; c0 += 8) {
-      float v[8];
+      for (int c0 = 0; c0 < 32; c0 += 8) {
+        float v[8];
 #pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        float s = 0.f;
+        for (int c = 0; c < 8; c += 2) {   // two channels per v_pk_fma_f32; w is tap-major [9][32], uniform index -> scalar loads
+          f32x2_t s = {0.f, 0.f};
 #pragma unroll
-        for (int q = 0; q < 9; ++q) s = fmaf(w[(c0 + c) * 9 + q], x[q], s);   // uniform index: the weights arrive by scalar loads
-        v[c] = relu_nan(s * scale[c0 + c] + shift[c0 + c]);
-      }
-      if constexpr (EB == 2) {
-        *reinterpret_cast<uint4*>(op + c0 * 2) =
-            make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
-      } else {
-        *reinterpret_cast<float4*>(op + c0 * 4) = make_float4(v[0], v[1], v[2], v[3]);
-        *reinterpret_cast<float4*>(op + c0 * 4 + 16) = make_float4(v[4], v[5], v[6], v[7]);
+          for (int q = 0; q < 9; ++q) {
+            const f32x2_t wq = {w[q * 32 + c0 + c], w[q * 32 + c0 + c + 1]}, xq = {x[q], x[q]};
+            s = __builtin_elementwise_fma(wq, xq, s);
+          }
+          v[c] = relu_nan(s[0] * scale[c0 + c] + shift[c0 + c]);
+          v[c + 1] = relu_nan(s[1] * scale[c0 + c + 1] + shift[c0 + c + 1]);
+        }
+        if constexpr (EB == 2) {
+          *reinterpret_cast<uint4*>(lp + c0 * 2) =
+              make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+        } else {
+          *reinterpret_cast<float4*>(lp + c0 * 4) = make_float4(v[0], v[1], v[2], v[3]);
+          *reinterpret_cast<float4*>(lp + c0 * 4 + 16) = make_float4(v[4], v[5], v[6], v[7]);
+        }
       }
     }
+    __syncthreads();
+    // rows are whole: the round's valid positions are a prefix (positions past the utterance's last row are not written)
+    const int nvalid = (tb - t0) * STEM_W - p0;   // valid positions of this round (may exceed 256)
+    unsigned char* ob = out + (((size_t)b * T + t0) * STEM_W + p0) * PB;
+    constexpr int CPP = PB / 16;                  // 16-B chunks per position
+#pragma unroll
+    for (int j = 0; j < CPP; ++j) {
+      const int id = j * 256 + tid, pos = id / CPP, part = id % CPP;
+      if (pos < nvalid) *reinterpret_cast<uint4*>(ob + (size_t)id * 16) = *reinterpret_cast<const uint4*>(stage + pos * PS + part * 16);
+    }
+    __syncthreads();
   }
 }
 

@@ -322,7 +322,13 @@ static int finalize_half(xt_handle* h) {
   const std::string sn = "sequence_network";
   std::vector<float> zero64(64, 0.f);  // the zero page the conv staging reads its zero padding from
   SK_TRY(upload(h, zero64.data(), zero64.size() * 4, &h->d_zeros));
-  SK_TRY(upload_f(h, T(h, sn + ".conv1.weight"), &h->stem_w));
+  {  // stem weights tap-major [9][32]: channel pairs are adjacent, which is what the packed-f32 FMAs of stem_kernel want
+    const auto& w = T(h, sn + ".conv1.weight");   // [32][1][3][3]
+    std::vector<float> wt(9 * 32);
+    for (int c = 0; c < 32; ++c)
+      for (int q = 0; q < 9; ++q) wt[q * 32 + c] = w[c * 9 + q];
+    SK_TRY(upload_f(h, wt, &h->stem_w));
+  }
   std::vector<float> sc, sh;
   fold_bn(h, sn + ".bn1", sc, sh);
   SK_TRY(upload_f(h, sc, &h->stem_scale));
