@@ -600,13 +600,13 @@ static int launch_cfg(const ConvArgs& a, hipStream_t st) {
 //                      T      CIN COUT S WIN TH WM WN MW NW  CK TAPS
 using B_L1   = ConvCfg<bf16_t,  32,  32, 1, 80,  8, 4, 1, 5, 1, 32, 9, 0, 0, true>;     // two persistent weight-resident workgroups per CU
 using B_L1S  = ConvCfg<bf16_t,  32,  32, 1, 80,  8, 4, 1, 5, 1, 32, 1, 0, 0, true>;
-using B_L2A  = ConvCfg<bf16_t,  32,  64, 2, 80,  8, 2, 2, 5, 1, 32, 9, 0, 0, true>;
+using B_L2A  = ConvCfg<bf16_t,  32,  64, 2, 80,  4, 2, 2, 3, 1, 32, 9, 2, 0, true>;     // 4-row tiles (47 KB): two persistent weight-resident WGs/CU instead of one 8-row WG (226 -> 177 us)
 using B_L2S  = ConvCfg<bf16_t,  32,  64, 2, 80,  8, 2, 2, 5, 1, 32, 1, 0, 0, true>;
 using B_L2   = ConvCfg<bf16_t,  64,  64, 1, 40,  8, 2, 2, 5, 1, 64, 9, 3, 4, true>;     // three workgroups per CU
-using B_L3A  = ConvCfg<bf16_t,  64, 128, 2, 40,  8, 1, 4, 5, 1, 64, 9>;
+using B_L3A  = ConvCfg<bf16_t,  64, 128, 2, 40,  4, 1, 4, 3, 1, 64, 9, 2, 0, true>;     // 4-row tiles (47 KB, 80 of 96 M-tile slots): several WGs/CU instead of one (163 -> 127 us)
 using B_L3S  = ConvCfg<bf16_t,  64, 128, 2, 40,  8, 1, 4, 5, 1, 64, 1>;
 using B_L3   = ConvCfg<bf16_t, 128, 128, 1, 20,  8, 1, 4, 5, 1, 128, 9, 3, 4, true>;    // three workgroups per CU: 53760 B = 42 LDS granules
-using B_L4A  = ConvCfg<bf16_t, 128, 256, 2, 20, 17, 1, 4, 6, 1, 64, 9>;    // 17-row tiles: T' = 51 = 3 x 17 at the 4 s benchmark length (16-row tiles computed 64 rows); NT = 128: grid.y = 2
+using B_L4A  = ConvCfg<bf16_t, 128, 256, 2, 20,  8, 1, 4, 3, 1, 64, 9, 2, 0, true>;     // 8-row tiles (46 KB): 147 -> 104 us; NT = 128: grid.y = 2
 using B_L4S  = ConvCfg<bf16_t, 128, 256, 2, 20, 16, 1, 4, 5, 1, 64, 1>;
 using B_L4   = ConvCfg<bf16_t, 256, 256, 1, 10, 17, 1, 4, 6, 1, 128, 9, 2>;   // 170 of 192 M-tile slots used; NT = 128: two workgroups per CU
 

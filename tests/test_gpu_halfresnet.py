@@ -204,3 +204,24 @@ def test_bf16_row_tile_boundaries_and_per_utterance(model):
             assert torch.equal(one[0], e16[i]), (i, frames[i])
     finally:
         model.compute_dtype = "fp32"
+
+
+def test_ab_paths_agree(gpu, monkeypatch):
+    """The A/B switches kept in the library (shortcut as a stored tensor / mel projection as a GEMM) are the older
+    formulations of the same arithmetic: they must agree with the default path (bf16 bit for bit on the shortcut side)."""
+    torch.manual_seed(21)
+    wav = 0.1 * torch.randn(3, 30000).cuda()
+    lens = [30000, 17000, 22222]
+    base = Xtractor(64, model_archi="halfresnet34", loss="aam", seed=5).to(gpu).eval()
+    out = {}
+    for dtype in ("fp32", "bf16"):
+        base.compute_dtype = dtype
+        out[dtype] = base(wav, is_eval=True, lengths=lens)[1]
+    for var in ("SIDEKIT_AMD_SHORTCUT_TENSOR", "SIDEKIT_AMD_MEL_GEMM"):
+        monkeypatch.setenv(var, "1")
+        alt = Xtractor(64, model_archi="halfresnet34", loss="aam", seed=5).to(gpu).eval()
+        for dtype in ("fp32", "bf16"):
+            alt.compute_dtype = dtype
+            e = alt(wav, is_eval=True, lengths=lens)[1]                 # the switch is read when the native handle is made (first forward)
+            assert rel(e, out[dtype]) < (2e-5 if dtype == "fp32" else 2e-2), (var, dtype)
+        monkeypatch.delenv(var)
