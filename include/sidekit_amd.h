@@ -98,7 +98,9 @@ int xt_debug_tap(xt_handle* h, const char* name, void* h_dst, size_t capacity, s
 /* Measurement: when on, every kernel launch of the forward is bracketed by HIP events recorded on
  * the launch stream.  xt_get_profile synchronises and returns, per slot, the summed device time (ms)
  * and the number of launches since the last reset.  Slots 0..10 are the 3x3 / 1x1 trunk convolution
- * shapes in the order L1, L1-shortcut, L2a, L2-shortcut, L2, L3a, L3-shortcut, L3, L4a, L4-shortcut, L4. */
+ * shapes in the order L1, L1-shortcut, L2a, L2-shortcut, L2, L3a, L3-shortcut, L3, L4a, L4-shortcut, L4.
+ * `on`: 0 = off, 1 = every slot, otherwise a mask with bit (slot + 1) set for each slot to bracket -- an event pair
+ * costs about 2 us of stream time, so a timed run brackets only the class it reports (bench.py: the dominant one). */
 #define XT_PROF_FRONTEND 11
 #define XT_PROF_STEM 12
 #define XT_PROF_SE_RES 13

@@ -114,7 +114,7 @@ struct xt_handle {
   int ring_cur = 0;
   bool norm_embedding = true;
   // per-kernel-class HIP-event profile (xt_set_profile)
-  bool profile = false;
+  uint32_t profile = 0;   // bit (slot + 1) per bracketed slot; 1 = all
   struct ProfRec { int slot; hipEvent_t a, b; };
   std::vector<ProfRec> prof_recs;
   std::vector<hipEvent_t> prof_pool;
@@ -469,7 +469,7 @@ __global__ void rows_to_bft_kernel(const float* __restrict__ src, float* __restr
 struct ProfScope {
   xt_handle* h; hipStream_t st; int slot; hipEvent_t a = nullptr, b = nullptr;
   ProfScope(xt_handle* h_, int slot_, hipStream_t st_) : h(h_), st(st_), slot(slot_) {
-    if (!h->profile) return;
+    if (!(h->profile == 1u || (h->profile >> (slot_ + 1)) & 1u)) return;
     auto get = [&]() { hipEvent_t e; if (!h->prof_pool.empty()) { e = h->prof_pool.back(); h->prof_pool.pop_back(); } else (void)hipEventCreate(&e); return e; };
     a = get(); b = get();
     (void)hipEventRecord(a, st);
@@ -973,7 +973,7 @@ int xt_set_norm_embedding(xt_handle* h, int32_t on) {
 
 int xt_set_profile(xt_handle* h, int32_t on) {
   SK_CHECK(h, SK_EARG, "null handle");
-  h->profile = on != 0;
+  h->profile = (uint32_t)on;
   return SK_OK;
 }
 

@@ -193,9 +193,15 @@ class Xtractor:
             out[n] = buf
         return out
 
-    def set_profile(self, on, dtype=None):
-        """Bracket every kernel launch of ``forward`` with HIP events on the launch stream (measurement only)."""
-        _lib.check(_lib.lib().xt_set_profile(self._handle(dtype), 1 if on else 0))
+    def set_profile(self, on, dtype=None, slots=None):
+        """Bracket the kernel launches of ``forward`` with HIP events on the launch stream (measurement only): all of
+        them, or only the named classes (``slots``, names as returned by ``get_profile``) -- an event pair costs stream time."""
+        mask = 1 if on else 0
+        if on and slots is not None:
+            mask = 0
+            for name in slots:
+                mask |= 1 << (_lib.PROF_NAMES.index(name) + 1)
+        _lib.check(_lib.lib().xt_set_profile(self._handle(dtype), mask))
 
     def get_profile(self, dtype=None, reset=True):
         """``{kernel class: (device ms, launches)}`` accumulated since the last reset."""

@@ -225,3 +225,20 @@ def test_ab_paths_agree(gpu, monkeypatch):
             e = alt(wav, is_eval=True, lengths=lens)[1]                 # the switch is read when the native handle is made (first forward)
             assert rel(e, out[dtype]) < (2e-5 if dtype == "fp32" else 2e-2), (var, dtype)
         monkeypatch.delenv(var)
+
+
+def test_profile_slots(model):
+    """xt_set_profile: every kernel class, or only the named ones (bench.py brackets the dominant class in its timed region)."""
+    wav = 0.1 * torch.randn(2, 16000).cuda()
+    model.set_profile(True)
+    model.get_profile(reset=True)
+    model(wav, is_eval=True)
+    full = model.get_profile(reset=True)
+    assert {"conv_L1", "conv_L4", "frontend", "stem", "se_residual", "pool_tail"} <= set(full) and full["conv_L1"][1] == 6
+    model.set_profile(True, slots=["stem", "conv_L3"])
+    model(wav, is_eval=True)
+    part = model.get_profile(reset=True)
+    assert set(part) == {"stem", "conv_L3"} and part["conv_L3"][1] == 11 and part["stem"][0] > 0
+    model.set_profile(False)
+    model(wav, is_eval=True)
+    assert model.get_profile(reset=True) == {}
