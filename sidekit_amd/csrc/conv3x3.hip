@@ -15,7 +15,12 @@
 //    scale/shift, ReLU and the squeeze-excite plane sums in registers, transposes the tile through the
 //    consumed LDS buffer and writes it as contiguous 16-B-per-lane NHWC rows;
 //  * per-utterance lengths: rows >= the utterance's own row count are read as zero
-//    padding and never written, so a padded batch reproduces each utterance run alone.
+//    padding and never written, so a padded batch reproduces each utterance run alone;
+//  * one template, four compile-time epilogue forms (plain / statistics for the SE gate / residual / residual with the
+//    first block's 1x1 shortcut convolution evaluated in place), two LDS images (padded, or pad-free and swizzled),
+//    per-shape occupancy: persistent weight-resident workgroups for the 32-channel inputs, three workgroups per
+//    CU at 168 registers for layers 2-3, small tiles for the stride-2 shapes (DESIGN.md section 4 has the measurements
+//    behind each choice).
 #include "kernels.h"
 
 namespace sk {
