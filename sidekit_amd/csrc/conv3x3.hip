@@ -378,18 +378,19 @@ void conv3x3_kernel(ConvArgs a) {
         const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane(((nt0 + j * C::WN + wn) * KX + ks) * 1024);
         wx[ks] = *reinterpret_cast<const uint4*>(scb + soff + (unsigned)lane * 16u);
       }
-      // constants first (vector-memory loads return in order: a constant fetched between the position loads below
-      // would wait behind them), then the block-input fragments one M-tile ahead of their use
-      f32x4 k1[4], k0[4], s2[4], h2[4];   // bn2 scale * gate, bn2 shift * gate, shortcut BN scale / shift
+      // x = (bn2(conv2) * gate) + bn_s(conv1x1(x_in)) = k1 * acc + [scale_s folded into the 1x1 weights] + k0 with
+      // k1 = scale2 * gate, k0 = shift2 * gate + shift_s: scale the accumulators, let the 1x1's MFMAs accumulate into
+      // them, add k0.  Constants are taken one channel group at a time (4 registers each), so the form fits the
+      // product configurations (168 registers at three workgroups per CU, resident weights in the persistent ones).
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const f32x4 sc = ld4(scale, g), sh = ld4(shift, g), gt = ld4(gate_b, g);
-        s2[g] = ld4(a.sc_scale, g);
-        h2[g] = ld4(a.sc_shift, g);
+        const f32x4 sc = ld4(scale, g), gt = ld4(gate_b, g);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { k1[g][q] = sc[q] * gt[q]; k0[g][q] = sh[q] * gt[q]; }
+        for (int i = 0; i < C::MW; ++i)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) accv[i][j][4 * g + q] *= sc[q] * gt[q];
       }
-      constexpr bool AHEAD = KX <= 4;
+      constexpr bool AHEAD = KX <= 4;   // block-input fragments one M-tile ahead of their use
       auto xload = [&](int i, uint4* dst) {
         const int m = (wm * C::MW + i) * 32 + r;
         const int ho = m / C::WOUT, wo = m % C::WOUT;
@@ -401,13 +402,9 @@ void conv3x3_kernel(ConvArgs a) {
       xload(0, xf);
 #pragma unroll
       for (int i = 0; i < C::MW; ++i) {
-        const int m = (wm * C::MW + i) * 32 + r;
         if constexpr (AHEAD) { if (i + 1 < C::MW) xload(i + 1, xn); }
-        f32x16 t;
 #pragma unroll
-        for (int q = 0; q < 16; ++q) t[q] = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < KX; ++ks) mma_step<T>(t, wx[ks], xf[ks]);
+        for (int ks = 0; ks < KX; ++ks) mma_step<T>(accv[i][j], wx[ks], xf[ks]);
         if (i + 1 < C::MW) {
           if constexpr (AHEAD) {
 #pragma unroll
@@ -416,20 +413,18 @@ void conv3x3_kernel(ConvArgs a) {
             xload(i + 1, xf);
           }
         }
-        unsigned char* lp = smem + m * OPS + (wn * 32 + 4 * h) * C::EB;
-        const bool store = !C::PARTIAL_M || m < C::MT;
+      }
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 sh = ld4(shift, g), gt = ld4(gate_b, g), h2 = ld4(a.sc_shift, g);
+#pragma unroll
+        for (int i = 0; i < C::MW; ++i) {
+          const int m = (wm * C::MW + i) * 32 + r;
+          unsigned char* lp = smem + m * OPS + (wn * 32 + 4 * h) * C::EB;
           float v[4];
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            // both addends are rounded to the storage type first, as when the shortcut is a stored tensor
-            float main_v = accv[i][j][4 * g + q] * k1[g][q] + k0[g][q];
-            float sc_v = t[4 * g + q] * s2[g][q] + h2[g][q];
-            if constexpr (C::EB == 2) { main_v = round_bf16(main_v); sc_v = round_bf16(sc_v); }
-            v[q] = relu_nan(main_v + sc_v);
-          }
-          if (store) {
+          for (int q = 0; q < 4; ++q) v[q] = relu_nan(accv[i][j][4 * g + q] + (sh[q] * gt[q] + h2[q]));
+          if (!C::PARTIAL_M || m < C::MT) {
             if constexpr (C::EB == 2) *reinterpret_cast<uint2*>(lp + 8 * g * 2) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
             else *reinterpret_cast<float4*>(lp + 8 * g * 4) = make_float4(v[0], v[1], v[2], v[3]);
           }
@@ -562,7 +557,7 @@ static int launch_cfg(const ConvArgs& a, hipStream_t st) {
   const int tiles = cdiv(a.Hout, C::TH), nwork = a.B * tiles;
   // weight-resident shapes: just the workgroups the chip holds at once (LDS and the compiled-for occupancy), persistent
   constexpr int NWV = C::WM * C::WN;
-  const int occ = (a.sc_wpack ? 1 : C::OCC) * 4 / NWV, by_lds = 160 * 1024 / C::LDS;
+  const int occ = ((a.sc_wpack && !a.sc_in) ? 1 : C::OCC) * 4 / NWV, by_lds = 160 * 1024 / C::LDS;   // the fused-shortcut kernels are compiled for one wave per SIMD
   const int resident_wgs = cu_count() * (occ < by_lds ? (occ > 0 ? occ : 1) : by_lds);
   dim3 grid((unsigned)((C::RESIDENT && !(a.dbg & 8) && nwork > resident_wgs) ? resident_wgs : nwork), C::COUT / C::NT);
   const dim3 block(NWV * 64);
@@ -580,12 +575,20 @@ static int launch_cfg(const ConvArgs& a, hipStream_t st) {
       return SK_OK;
     }
   }
-  SK_CHECK(!a.sc_wpack, SK_EARG, "this convolution shape has no fused-shortcut form");
+  SK_CHECK(!a.sc_wpack || a.sc_in, SK_EARG, "this convolution shape has no fused-shortcut form");
   if constexpr (C::TAPS == 9) {
     if (a.se_part) {
       hipLaunchKernelGGL((conv3x3_kernel<C, false, FORM_STATS>), grid, block, 0, st, a);
       SK_HIP(hipGetLastError());
       return SK_OK;
+    }
+    if constexpr (C::S == 1 && C::CIN == C::COUT) {
+      if (a.gate && a.sc_in) {  // first block of a layer: the 1x1 shortcut conv of the block input evaluated in this epilogue
+        SK_CHECK(a.sc_wpack && a.sc_scale && a.sc_shift && !a.shortcut, SK_EARG, "in-place shortcut form: bad arguments");
+        hipLaunchKernelGGL((conv3x3_kernel<C, false, FORM_RESID_SC>), grid, block, 0, st, a);
+        SK_HIP(hipGetLastError());
+        return SK_OK;
+      }
     }
     if constexpr (C::S == 1) {
       if (a.gate) {
@@ -662,33 +665,7 @@ int conv_geom(int shape, int dtype, ConvGeom* g) {
   return SK_EARG;
 }
 
-// residual form with the in-place 1x1 shortcut (first block of a layer): four launches per forward, on the
-// two-workgroups-per-CU configurations (the epilogue holds the shortcut accumulators next to the main ones)
-using B_L1Z = ConvCfg<bf16_t,  32,  32, 1, 80,  8, 4, 1, 5, 1, 32, 9, 2, 6, true>;
-using B_L2Z = ConvCfg<bf16_t,  64,  64, 1, 40,  8, 2, 2, 5, 1, 64, 9, 2, 0, true>;
-using B_L3Z = ConvCfg<bf16_t, 128, 128, 1, 20,  8, 1, 4, 5, 1, 128, 9>;
-using B_L4Z = B_L4;
-
-template <class C>
-static int launch_rsc(const ConvArgs& a, hipStream_t st) {
-  SK_CHECK(a.gate && a.sc_wpack && a.sc_scale && a.sc_shift && !a.se_part && !a.shortcut, SK_EARG, "in-place shortcut form: bad arguments");
-  const int tiles = cdiv(a.Hout, C::TH);
-  hipLaunchKernelGGL((conv3x3_kernel<C, false, FORM_RESID_SC>), dim3((unsigned)(a.B * tiles), C::COUT / C::NT), dim3(C::WM * C::WN * 64), 0, st, a);
-  SK_HIP(hipGetLastError());
-  return SK_OK;
-}
-
 int launch_conv(int shape, int dtype, const ConvArgs& a, hipStream_t st) {
-  if (a.sc_in) {
-    switch (shape) {
-      case CONV_L1: return dtype == DT_BF16 ? launch_rsc<B_L1Z>(a, st) : launch_rsc<F_L1>(a, st);
-      case CONV_L2: return dtype == DT_BF16 ? launch_rsc<B_L2Z>(a, st) : launch_rsc<F_L2>(a, st);
-      case CONV_L3: return dtype == DT_BF16 ? launch_rsc<B_L3Z>(a, st) : launch_rsc<F_L3>(a, st);
-      case CONV_L4: return dtype == DT_BF16 ? launch_rsc<B_L4Z>(a, st) : launch_rsc<F_L4>(a, st);
-    }
-    set_error("launch_conv: shape %d has no in-place shortcut form", shape);
-    return SK_EARG;
-  }
   switch (shape) {
 #define X(id, name) \
   case id: return dtype == DT_BF16 ? launch_cfg<B_##name>(a, st) : launch_cfg<F_##name>(a, st);

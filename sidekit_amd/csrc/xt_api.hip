@@ -48,6 +48,7 @@ struct Block {
   float* se_w1 = nullptr;
   float* se_w2 = nullptr;
   void* w2t = nullptr;   // conv2 weights as the MFMA consumes them, [tap][ci][co] bf16 / f32 (SE gate pre-computation)
+  void* sc_wfold = nullptr;   // shortcut 1x1 weights with the shortcut BN scale folded in (row co times scale[co]), fragment order
   int C, li;
 };
 
@@ -344,7 +345,20 @@ static int finalize_half(xt_handle* h) {
       SK_TRY(make_conv(h, b.c1, bi == 0 ? first_shape[li] : rest_shape[li], p + ".conv1.weight", p + ".bn1"));
       SK_TRY(make_conv(h, b.c2, rest_shape[li], p + ".conv2.weight", p + ".bn2"));
       b.has_sc = bi == 0;
-      if (b.has_sc) SK_TRY(make_conv(h, b.sc, sc_shape[li], p + ".shortcut.0.weight", p + ".shortcut.1"));
+      if (b.has_sc) {
+        SK_TRY(make_conv(h, b.sc, sc_shape[li], p + ".shortcut.0.weight", p + ".shortcut.1"));
+        // in-place shortcut (conv2's epilogue): bn_s(conv1x1(x)) = (scale_s * W) x + shift_s accumulates straight into
+        // conv2's (already gate- and BN-scaled) accumulators, so the BN scale of the shortcut goes into its weights
+        const HostTensor& w = h->tensors[p + ".shortcut.0.weight"];
+        std::vector<float> scs, shs;
+        fold_bn(h, p + ".shortcut.1", scs, shs);
+        std::vector<float> wf(w.data.size());
+        const size_t per = wf.size() / b.sc.g.cout;
+        for (size_t i = 0; i < wf.size(); ++i) wf[i] = w.data[i] * scs[i / per];
+        std::vector<unsigned char> packed(conv_pack_bytes(b.sc.g));
+        conv_pack_weights(b.sc.g, wf.data(), (int)(w.shape[2] * w.shape[3]), packed.data());
+        SK_TRY(upload(h, packed.data(), packed.size(), &b.sc_wfold));
+      }
       {
         const auto& w2 = T(h, p + ".conv2.weight");  // [co][ci][3][3]
         const int Cb = b.C;
@@ -651,7 +665,7 @@ static int half_from_feats(xt_handle* h, const float* feats, long sb, long sf, l
     a.halvings_in = li; a.Hin = Hl[li]; a.Hout = Hl[li]; a.relu = 0;
     if (inplace_sc) {
       a.shortcut = nullptr; a.sc_in = X; a.sc_hin = Hl[lin];
-      a.sc_wpack = b.sc.wpack; a.sc_scale = b.sc.scale; a.sc_shift = b.sc.shift;
+      a.sc_wpack = b.sc_wfold; a.sc_scale = b.sc.scale; a.sc_shift = b.sc.shift;
     }
     { ProfScope ps(h, b.c2.shape, st); SK_TRY(launch_conv(b.c2.shape, dt, a, st)); }
     std::swap(X, O2);
