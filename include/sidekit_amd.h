@@ -61,8 +61,10 @@ const char* xt_key_name(xt_handle* h, int32_t i);
 /* Fold BatchNorm, repack to kernel layouts, upload.  Fails with SK_ESHAPE naming the first missing key. */
 int xt_finalize(xt_handle* h);
 
-/* Size the device workspace for batches up to max_batch utterances x max_samples samples each
- * (TDNN: max_batch x max_samples bounds the total). */
+/* Size the device workspace for a batch shape of max_batch utterances x max_samples samples each (TDNN: max_batch x
+ * max_samples bounds the total).  Buffers only grow; a later forward runs when ONE reserved shape covers its batch in
+ * both dimensions, so reserving (256, 64000) and (1, 20000000) sizes the workspace for those two products, not for
+ * 256 x 20000000. */
 int xt_reserve(xt_handle* h, int32_t max_batch, int64_t max_samples);
 
 /* Xtractor.forward(x, is_eval=True) (sidekit/nnet/xvector.py:876-907).

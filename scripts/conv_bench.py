@@ -7,8 +7,8 @@ if os.environ.get('SK_LIB'):  # A/B against another build of the library
     _lib.LIB_PATH = os.path.abspath(os.environ['SK_LIB'])
 lib = _lib.lib()
 torch.cuda.init(); torch.zeros(1).cuda()
-names = list(_lib.PROF_NAMES[:11]) + ['X0(L1 3WG)', 'X1(L2 2WG)', 'X2(L3 2WG padded)', 'X3(L4 TH16)']
-Ts = {0: 401, 1: 401, 2: 401, 3: 401, 4: 201, 5: 201, 6: 201, 7: 101, 8: 101, 9: 101, 10: 51, 11: 401, 12: 201, 13: 101, 14: 51}
+names = list(_lib.PROF_NAMES[:11]) + ['X0(L1 3WG)', 'X1(L2 2WG)', 'X2(L3 2WG padded)', 'X3(L4 TH16)', 'X4(L3 r01 linear)', 'X5(L4 r01 linear)', 'X6(L2 r01 linear)', 'X7(L1 r01 linear)']
+Ts = {0: 401, 1: 401, 2: 401, 3: 401, 4: 201, 5: 201, 6: 201, 7: 101, 8: 101, 9: 101, 10: 51, 11: 401, 12: 201, 13: 101, 14: 51, 15: 101, 16: 51, 17: 201, 18: 401}
 shapes = [int(x) for x in sys.argv[1].split(",")] if len(sys.argv) > 1 else [0, 4, 7, 10]
 STAMPS = os.environ.get("STAMPS", "0") == "1"
 variants = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0, 1, 2, 3, 4, 6]
@@ -24,6 +24,7 @@ for sh in shapes:
             continue
         txt = f"v{v}={ms.value*1e3:.0f}us"
         if STAMPS:
-            txt += " [cyc: issue %d | land+bar %d | kloop %d | bar+epi %d | bar %d | out %d | WG total %d]" % (ph[0], ph[1], ph[2], ph[3], ph[4], ph[5], ph[7])
+            txt += " [cyc: issue %d | land+bar %d | kloop %d | bar+epi %d | bar %d | out %d | WG total %d | clock %.2f GHz]" % (
+                ph[0], ph[1], ph[2], ph[3], ph[4], ph[5], ph[7], ph[7] / max(ph[6], 1.0) * 0.1)
         row.append(txt)
     print(names[sh], " ".join(row), flush=True)

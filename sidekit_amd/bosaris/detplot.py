@@ -43,22 +43,25 @@ def rocch(tar_scores, nontar_scores):
 
 
 def rocch2eer(pmiss, pfa):
-    """Equal error rate from the hull vertices: the highest intersection of a hull segment with the
-    diagonal pmiss == pfa."""
-    eer = 0
-    for i in range(pfa.shape[0] - 1):
-        xx, yy = pfa[i:i + 2], pmiss[i:i + 2]
-        assert (xx[1] <= xx[0]) & (yy[0] <= yy[1]), 'pmiss and pfa have to be sorted'
-        XY = numpy.column_stack((xx, yy))
-        dd = numpy.dot(numpy.array([1, -1]), XY)
-        if numpy.min(numpy.abs(dd)) == 0:
-            eerseg = 0
-        else:
-            # the segment's line a*x + b*y = 1 meets x == y at 1 / (a + b)
-            seg = numpy.linalg.solve(XY, numpy.array([[1], [1]]))
-            eerseg = 1 / (numpy.sum(seg))
-        eer = max([eer, eerseg])
-    return eer
+    """Equal error rate from the hull vertices (``detplot.py:354-387``).
+
+    Every hull edge (pfa_i, pmiss_i) -> (pfa_i+1, pmiss_i+1) lies on a line ``a x + b y = 1``; that line crosses the
+    diagonal ``x == y`` at ``1 / (a + b)`` and the EER is the largest crossing.  Axis-parallel edges contribute 0.  All
+    edges go through ONE batched ``numpy.linalg.solve`` (the same LAPACK 2x2 factorisation per edge as a per-edge call,
+    so the value is bit-identical to the reference's loop)."""
+    pmiss = numpy.asarray(pmiss, dtype=numpy.float64)
+    pfa = numpy.asarray(pfa, dtype=numpy.float64)
+    if pfa.shape[0] < 2:
+        return 0
+    edges = numpy.stack((numpy.stack((pfa[:-1], pmiss[:-1]), axis=1), numpy.stack((pfa[1:], pmiss[1:]), axis=1)), axis=1)
+    assert bool(numpy.all(edges[:, 1, 0] <= edges[:, 0, 0]) and numpy.all(edges[:, 0, 1] <= edges[:, 1, 1])), \
+        'pmiss and pfa have to be sorted'
+    slanted = (edges[:, 0, 0] != edges[:, 1, 0]) & (edges[:, 0, 1] != edges[:, 1, 1])
+    if not slanted.any():
+        return 0
+    coef = numpy.linalg.solve(edges[slanted], numpy.ones((int(slanted.sum()), 2, 1)))
+    crossing = 1 / (coef[:, 0, 0] + coef[:, 1, 0])
+    return max(0, crossing.max())
 
 
 def sigmoid(log_odds):
@@ -82,16 +85,13 @@ def logit_effective_prior(Ptar, cmiss, cfa):
 
 
 def fast_minDCF(tar, non, plo, normalize=False):
-    """``(minDCF, Pmiss, Pfa, prbep, eer)`` at prior log-odds ``plo``."""
-    Pmiss, Pfa = rocch(tar, non)
-    Nmiss = Pmiss * tar.shape[0]
-    Nfa = Pfa * non.shape[0]
-    prbep = rocch2eer(Nmiss, Nfa)
-    eer = rocch2eer(Pmiss, Pfa)
-    Ptar, Pnon = sigmoid(plo), sigmoid(-plo)
-    cdet = numpy.dot(numpy.array([[Ptar, Pnon]]), numpy.vstack((Pmiss, Pfa)))
-    ii = numpy.argmin(cdet, axis=1)
-    minDCF = cdet[0, ii][0]
-    if normalize:
-        minDCF = minDCF / min([Ptar, Pnon])
-    return minDCF, Pmiss[ii][0], Pfa[ii][0], prbep, eer
+    """``(minDCF, Pmiss, Pfa, prbep, eer)`` at prior log-odds ``plo`` (``detplot.py:454-511``): the detection cost
+    ``P_tar Pmiss + (1 - P_tar) Pfa`` is linear between hull vertices, so its minimum over thresholds is attained at a
+    vertex; ``prbep`` is the break-even point of the hull in counts (misses == false alarms)."""
+    p_miss, p_fa = rocch(tar, non)
+    n_tar, n_non = tar.shape[0], non.shape[0]
+    prior_tar, prior_non = sigmoid(plo), sigmoid(-plo)
+    cost = numpy.dot(numpy.array([[prior_tar, prior_non]]), numpy.vstack((p_miss, p_fa)))[0]
+    best = int(numpy.argmin(cost))
+    dcf = cost[best] / min(prior_tar, prior_non) if normalize else cost[best]
+    return dcf, p_miss[best], p_fa[best], rocch2eer(p_miss * n_tar, p_fa * n_non), rocch2eer(p_miss, p_fa)

@@ -104,7 +104,7 @@ struct xt_handle {
   std::vector<TdnnLayer> tdnn;
 
   // workspace
-  int max_batch = 0; int64_t max_samples = 0;
+  std::vector<std::pair<int, int64_t>> reserved;   // (batch, samples) shapes xt_reserve has sized the workspace for: a batch runs when one of them covers it in BOTH dimensions
   DevBuf ws_S, ws_feat, ws_act[4], ws_se, ws_col, ws_edge, ws_splitk, ws_gate, ws_ctx, ws_rb, ws_h, ws_e, ws_pooled, ws_pre, ws_int;
   // pinned staging ring for per-utterance integers
   static constexpr int RING = 4;
@@ -643,6 +643,12 @@ static int half_from_feats(xt_handle* h, const float* feats, long sb, long sf, l
     const bool inplace_sc = first && !h->shortcut_tensor;
     const bool fuse_sc = first && !inplace_sc && b.c1.g.stride == 2 && b.c1.g.nw == 1 && b.sc.g.ck == b.c1.g.ck;
     if (fuse_sc) { a.sc_wpack = b.sc.wpack; a.sc_scale = b.sc.scale; a.sc_shift = b.sc.shift; a.sc_out = SC; }
+    {
+      const size_t tiles1 = (size_t)cdiv(Hl[li], b.c1.g.th);
+      SK_CHECK((size_t)B * tiles1 * b.c1.g.wm * b.C * 4 <= h->ws_se.bytes && (size_t)B * tiles1 * 2 * b.C * 4 <= h->ws_col.bytes &&
+               (size_t)B * 6 * b.C * 4 <= h->ws_edge.bytes && (size_t)B * b.C * 4 <= h->ws_gate.bytes, SK_EWORKSPACE,
+               "SE statistics workspace too small for %d x %d frames (xt_reserve)", B, T);
+    }
     { ProfScope ps(h, b.c1.shape, st); SK_TRY(launch_conv(b.c1.shape, dt, a, st)); }
     a.sc_wpack = nullptr;
     const void* shortcut = first ? SC : X;
@@ -898,8 +904,18 @@ int xt_reserve(xt_handle* h, int32_t max_batch, int64_t max_samples) {
   if (h->cfg.arch == XT_ARCH_HALFRESNET34) {
     const size_t EB = h->cfg.dtype == XT_BF16 ? 2 : 4;
     for (int i = 0; i < 4; ++i) SK_TRY(h->ws_act[i].ensure(R * 80 * 32 * EB));
-    SK_TRY(h->ws_se.ensure(B * ((T + 7) / 8 + 1) * 4 * 32 * 4 * 2));
-    SK_TRY(h->ws_col.ensure(B * ((T + 7) / 8 + 1) * 2 * 32 * 4 * 2));
+    // SE statistics of the statistics-form convolutions: [B][row tiles][wave rows][C] totals and [B][row tiles][2][C] column
+    // sums, sized from the largest first convolution of a block (short utterances: one 2-KB tile of layer 4 per utterance
+    // outgrows a per-frame estimate)
+    size_t se_b = 0, col_b = 0;
+    for (const Block& b : h->blocks) {
+      const size_t tiles = (size_t)cdiv(halve((int)T, b.li), b.c1.g.th);
+      const size_t s1 = B * tiles * b.c1.g.wm * b.C * 4, s2 = B * tiles * 2 * b.C * 4;
+      se_b = s1 > se_b ? s1 : se_b;
+      col_b = s2 > col_b ? s2 : col_b;
+    }
+    SK_TRY(h->ws_se.ensure(se_b));
+    SK_TRY(h->ws_col.ensure(col_b));
     SK_TRY(h->ws_edge.ensure(B * 6 * 256 * 4));
     SK_TRY(h->ws_gate.ensure(B * 256 * 4));
     const size_t H4 = (size_t)halve((int)T, 3);
@@ -914,7 +930,9 @@ int xt_reserve(xt_handle* h, int32_t max_batch, int64_t max_samples) {
     SK_TRY(h->ws_act[3].ensure(R * f.n_mels * 4));
     SK_TRY(h->ws_pooled.ensure(B * 3072 * 4));
   }
-  h->max_batch = max_batch; h->max_samples = max_samples;
+  bool covered = false;
+  for (auto& r : h->reserved) covered = covered || (r.first >= max_batch && r.second >= max_samples);
+  if (!covered) h->reserved.push_back({max_batch, max_samples});
   return SK_OK;
 }
 
@@ -922,10 +940,11 @@ static int check_run(xt_handle* h, int B, int64_t L_samples) {
   SK_CHECK(h, SK_EARG, "null handle");
   SK_CHECK(h->finalized, SK_ESTATE, "forward before xt_finalize (load_state_dict)");
   SK_CHECK(B > 0, SK_EARG, "empty batch");
-  SK_CHECK(h->max_batch > 0, SK_ESTATE, "forward before xt_reserve");
-  SK_CHECK(B <= h->max_batch && L_samples <= h->max_samples, SK_EWORKSPACE,
-           "batch of %d x %lld samples exceeds the reserved workspace (%d x %lld): call xt_reserve", B, (long long)L_samples,
-           h->max_batch, (long long)h->max_samples);
+  SK_CHECK(!h->reserved.empty(), SK_ESTATE, "forward before xt_reserve");
+  bool covered = false;
+  for (auto& r : h->reserved) covered = covered || (r.first >= B && r.second >= L_samples);
+  SK_CHECK(covered, SK_EWORKSPACE, "batch of %d x %lld samples exceeds every reserved workspace shape: call xt_reserve(%d, %lld)", B,
+           (long long)L_samples, B, (long long)L_samples);
   SK_HIP(hipSetDevice(h->device));
   return SK_OK;
 }
@@ -1021,8 +1040,25 @@ int sk_bench_conv(int32_t shape, int32_t dtype, int32_t B, int32_t T, int32_t it
   SK_HIP(hipMalloc(&in, in_b)); SK_HIP(hipMalloc(&out, out_b)); SK_HIP(hipMalloc(&w, conv_pack_bytes(g) + 4096));
   SK_HIP(hipMalloc(&zeros, 256)); SK_HIP(hipMalloc((void**)&sc, g.cout * 4)); SK_HIP(hipMalloc((void**)&sh, g.cout * 4));
   SK_HIP(hipMalloc((void**)&se, (size_t)B * (hout / g.th + 2) * (g.wm > 4 ? g.wm : 4) * g.cout * 4));
-  SK_HIP(hipMemset(in, 0x3c, in_b)); SK_HIP(hipMemset(w, 0x3c, conv_pack_bytes(g))); SK_HIP(hipMemset(zeros, 0, 256));
-  SK_HIP(hipMemset(sc, 0, g.cout * 4)); SK_HIP(hipMemset(sh, 0, g.cout * 4));
+  SK_HIP(hipMemset(zeros, 0, 256));
+  {  // random operands (uniform in [-1, 1)): constant fills toggle no bits and let the chip hold a clock real data never sees
+    auto fill = [&](void* dst, size_t bytes, float amp) -> int {
+      std::vector<uint32_t> hbuf(bytes / 4 + 1);
+      uint32_t x = 0x9E3779B9u;
+      for (auto& v : hbuf) {
+        auto next = [&]() { x = x * 1664525u + 1013904223u; return (float)((x >> 8) & 0xffff) / 32768.f - 1.f; };
+        if (g.eb == 2) v = (uint32_t)f32_to_bf16(amp * next()) | ((uint32_t)f32_to_bf16(amp * next()) << 16);
+        else v = __builtin_bit_cast(uint32_t, amp * next());
+      }
+      SK_HIP(hipMemcpy(dst, hbuf.data(), bytes, hipMemcpyHostToDevice));
+      return SK_OK;
+    };
+    SK_TRY(fill(in, in_b, 1.f));
+    SK_TRY(fill(w, conv_pack_bytes(g), 0.05f));
+    std::vector<float> ones(g.cout, 1.f), zs(g.cout, 0.f);
+    SK_HIP(hipMemcpy(sc, ones.data(), g.cout * 4, hipMemcpyHostToDevice));
+    SK_HIP(hipMemcpy(sh, zs.data(), g.cout * 4, hipMemcpyHostToDevice));
+  }
   ConvArgs a;
   memset(&a, 0, sizeof(a));
   a.in = in; a.wpack = w; a.scale = sc; a.shift = sh; a.out = out; a.se_part = nullptr; a.zeros = zeros;
@@ -1036,7 +1072,11 @@ int sk_bench_conv(int32_t shape, int32_t dtype, int32_t B, int32_t T, int32_t it
   }
   if (variant & 16) {  // residual-mode epilogue
     SK_HIP(hipMalloc((void**)&gate, (size_t)B * g.cout * 4)); SK_HIP(hipMalloc(&scut, out_b));
-    SK_HIP(hipMemset(gate, 0, (size_t)B * g.cout * 4)); SK_HIP(hipMemset(scut, 0, out_b));
+    {
+      std::vector<float> gv((size_t)B * g.cout, 0.5f);
+      SK_HIP(hipMemcpy(gate, gv.data(), gv.size() * 4, hipMemcpyHostToDevice));
+      SK_HIP(hipMemcpy(scut, in, out_b < in_b ? out_b : in_b, hipMemcpyDeviceToDevice));   // random shortcut rows
+    }
     a.gate = gate; a.shortcut = scut;
   }
   if (phase_cycles) { SK_HIP(hipMalloc((void**)&stamps, (size_t)nblk * 64)); SK_HIP(hipMemset(stamps, 0, (size_t)nblk * 64)); a.stamps = stamps; }
@@ -1058,6 +1098,7 @@ int sk_bench_conv(int32_t shape, int32_t dtype, int32_t B, int32_t T, int32_t it
       if (!hs[(size_t)i * 8 + 6]) continue;
       for (int k = 0; k < 6; ++k) phase_cycles[k] += (double)(hs[(size_t)i * 8 + k + 1] - hs[(size_t)i * 8 + k]);
       phase_cycles[7] += (double)(hs[(size_t)i * 8 + 6] - hs[(size_t)i * 8]);
+      phase_cycles[6] += (double)hs[(size_t)i * 8 + 7];   // 100 MHz ticks of the same span
       ++n;
     }
     for (int k = 0; k < 8; ++k) phase_cycles[k] /= (n ? n : 1);

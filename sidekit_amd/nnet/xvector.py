@@ -288,18 +288,20 @@ class Xtractor:
                 lib.xt_destroy(h)
                 raise
         self._handles[key] = h
-        self._reserved[key] = (0, 0)
+        self._reserved[key] = []
         return h
 
     def _reserve(self, h, B, L):
+        """Size the workspace for a (B, L) batch unless a shape reserved earlier covers it in both dimensions: buffers grow to
+        the largest B x L product actually requested, never to max(B) x max(L) of unrelated calls."""
         key = next(k for k, v in self._handles.items() if v is h)
-        mb, ml = self._reserved[key]
-        if B > mb or L > ml:
-            mb, ml = max(B, mb), max(L, ml)
-            with torch.cuda.device(self.device):
-                torch.cuda.synchronize(self.device)
-                _lib.check(_lib.lib().xt_reserve(h, mb, ml))
-            self._reserved[key] = (mb, ml)
+        shapes = self._reserved[key]
+        if any(b >= B and l >= L for b, l in shapes):
+            return
+        with torch.cuda.device(self.device):
+            torch.cuda.synchronize(self.device)
+            _lib.check(_lib.lib().xt_reserve(h, B, L))
+        self._reserved[key] = [(b, l) for b, l in shapes if not (b <= B and l <= L)] + [(B, L)]
 
     def _drop_handles(self):
         if self._handles:
