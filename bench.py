@@ -12,9 +12,19 @@ prints ONE JSON line.  Two extra objects ride on that line:
 
   roofline     the dominant kernel (the trunk convolution shape with the largest summed device
                time), its algorithmic bytes or FLOPs per launch over its mean launch duration
-               measured with HIP events on the launch stream during the timed steps;
+               measured with HIP events on the launch stream during the timed steps.  Two shapes
+               (layer 1: HBM-bound, layer 3: MFMA-bound) are within a percent of each other, so the
+               timed region brackets the TWO largest classes, the runner-up rides along as
+               `co_dominant`, and `trunk` carries the time-weighted fraction over every trunk
+               convolution -- none of the three moves with run-to-run noise;
   cpu_baseline the oracle's CPU restatement of the same forward, timed on this box's host cores
-               on a bounded sample (rank 0, N = 1 only).
+               on a bounded sample at batch 16 and batch 1 (rank 0, N = 1 only).
+
+`--gpus N` (N > 1) started WITHOUT torch.distributed.run in the environment launches its N ranks
+itself: a fresh `python -m torch.distributed.run ... bench.py` child is created before this process
+has touched the GPU, its output is relayed and its exit code returned.  `--dry-run` replaces the GPU
+step by a CPU stand-in over gloo (launch / rendezvous / gather / timing plumbing only; used by the
+CPU test-suite, never a measurement).
 """
 import argparse
 import json
@@ -68,60 +78,163 @@ def conv_work(name, B, T, eb):
     return flops + n3 * sc_flops / n, nbytes
 
 
-def roofline(prof, B, T, dtype):
+def class_roofline(name, ms, n, B, T, dtype, traffic_table):
+    """Roofline record of one trunk convolution class from its summed device time `ms` over `n` launches."""
     eb = 2 if dtype == "bf16" else 4
-    convs = {k: v for k, v in prof.items() if k in CONV_SHAPES}
-    if not convs:
-        return None
-    name = max(convs, key=lambda k: convs[k][0])
-    ms, n = convs[name]
     dur = ms / n * 1e-3
     flops, nbytes = conv_work(name, B, T, eb)
     peak_tf = MFMA_BF16_PEAK_TF if dtype == "bf16" else MFMA_F32_PEAK_TF
     ridge = peak_tf * 1e12 / (HBM_PEAK_GBS * 1e9)
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath):
-        with open(tpath) as f:
-            traffic = json.load(f).get(dtype, {}).get(name)
     if flops / nbytes < ridge:
         ach = nbytes / dur / 1e9
         r = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS}
     else:
         ach = flops / dur / 1e12
         r = {"bound": "mfma", "achieved": ach, "peak": peak_tf, "unit": "TFLOP/s", "frac": ach / peak_tf}
-    r.update({"traffic": traffic, "kernel": f"conv3x3_kernel<{name[5:]}, {dtype}>", "launch_us": dur * 1e6, "launches": n,
-              "alg_bytes_per_launch": nbytes, "alg_flops_per_launch": flops,
-              "per_class_ms_per_step": None})
+    r.update({"traffic": traffic_table.get(name), "kernel": f"conv3x3_kernel<{name[5:]}, {dtype}>", "launch_us": dur * 1e6, "launches": n,
+              "alg_bytes_per_launch": nbytes, "alg_flops_per_launch": flops})
     return r
 
 
-def cpu_baseline(seconds, budget_s=12.0):
-    """The oracle (torch-CPU restatement of the reference forward) on this box's host cores."""
+def roofline(prof, B, T, dtype, per_class_ms=None):
+    """`prof`: {class: (ms, launches)} of the timed region (the two largest classes, or all).  Returns the record of the
+    largest class with the runner-up as `co_dominant` and the time-weighted trunk aggregate as `trunk`."""
+    convs = {k: v for k, v in prof.items() if k in CONV_SHAPES and v[1]}
+    if not convs:
+        return None
+    traffic = {}
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        with open(tpath) as f:
+            traffic = json.load(f).get(dtype, {})
+    order = sorted(convs, key=lambda k: -convs[k][0])
+    r = class_roofline(order[0], *convs[order[0]], B, T, dtype, traffic)
+    if len(order) > 1:
+        r["co_dominant"] = class_roofline(order[1], *convs[order[1]], B, T, dtype, traffic)
+    if per_class_ms:   # every trunk class (warmup table): sum of roofline-bound times over sum of measured times
+        eb = 2 if dtype == "bf16" else 4
+        peak_tf = MFMA_BF16_PEAK_TF if dtype == "bf16" else MFMA_F32_PEAK_TF
+        t_meas = t_bound = 0.0
+        for name, ms in per_class_ms.items():
+            if name not in CONV_SHAPES:
+                continue
+            flops, nbytes = conv_work(name, B, T, eb)
+            n = sum(CONV_FORMS[name])
+            t_bound += n * max(flops / (peak_tf * 1e12), nbytes / (HBM_PEAK_GBS * 1e9)) * 1e3
+            t_meas += ms
+        if t_meas > 0:
+            r["trunk"] = {"frac_time_weighted": t_bound / t_meas, "roofline_ms_per_step": t_bound, "measured_ms_per_step": t_meas,
+                          "note": "sum over trunk convolution classes of launches x max(FLOPs / MFMA peak, bytes / HBM peak) over their measured time"}
+    r["per_class_ms_per_step"] = None
+    return r
+
+
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(seconds, budget_s=20.0):
+    """The oracle (torch-CPU restatement of the reference forward) on this box's host cores: batch 16 and batch 1
+    (SURVEY 8d), core count and CPU model stated."""
     import torch
     from oracle import xvector as oxv
     from sidekit_amd.nnet.weights import seeded_state_dict
-    cores = os.cpu_count() or 1
+    visible = os.cpu_count() or 1
     try:
-        cores = len(os.sched_getaffinity(0))
+        visible = len(os.sched_getaffinity(0))
     except Exception:
         pass
-    cores = min(cores, 16)  # a one-GPU box's CPU share; more threads only oversubscribe the intra-op pool
+    cores = min(visible, 16)  # a one-GPU box's CPU share; more threads only oversubscribe the intra-op pool
     torch.set_num_threads(cores)
     sd = seeded_state_dict("halfresnet34", 7205, seed=1234)
-    B = 8
-    torch.manual_seed(0)
-    wav = 0.1 * torch.randn(B, int(seconds * 16000))
-    with torch.no_grad():
-        oxv.halfresnet34_forward(wav, sd)  # warm-up
-        t0 = time.perf_counter()
-        it = 0
-        while time.perf_counter() - t0 < budget_s and it < 64:
-            oxv.halfresnet34_forward(wav, sd)
-            it += 1
-        dt = time.perf_counter() - t0
-    return {"value": B * it / dt, "unit": "x-vectors/s", "cores": cores, "kind": "port",
-            "sample": f"{it} batches of {B} synthetic {seconds:g} s utterances, fp32, torch-CPU oracle (oracle/xvector.py)"}
+    rates, samples = {}, []
+    for B, share in ((16, 0.65), (1, 0.35)):
+        torch.manual_seed(0)
+        wav = 0.1 * torch.randn(B, int(seconds * 16000))
+        with torch.no_grad():
+            oxv.halfresnet34_forward(wav, sd)  # warm-up
+            t0 = time.perf_counter()
+            it = 0
+            while time.perf_counter() - t0 < budget_s * share and it < 64:
+                oxv.halfresnet34_forward(wav, sd)
+                it += 1
+            dt = time.perf_counter() - t0
+        rates[B] = B * it / dt
+        samples.append(f"{it} batches of {B}")
+    return {"value": rates[16], "unit": "x-vectors/s", "cores": cores, "kind": "port", "cores_visible": visible, "cpu_model": cpu_model(),
+            "value_batch1": rates[1], "value_batch16": rates[16],
+            "sample": f"{' and '.join(samples)} synthetic {seconds:g} s utterances, fp32, torch-CPU oracle (oracle/xvector.py), {cores} threads"}
+
+
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launch_ranks(n, argv):
+    """Start `n` ranks of this script under torch.distributed.run as a fresh child process and relay its output.  Called
+    before anything in this process has touched the GPU (no exec of a GPU-initialised process, no fork after HIP init)."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)   # stderr is inherited
+    for line in proc.stdout:
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    return proc.wait()
+
+
+def dry_run(args):
+    """CPU stand-in of the benchmark loop over gloo: same launch / barrier / gather / MAX-over-ranks / JSON plumbing, no GPU work."""
+    import torch
+    import torch.distributed as dist
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    use_dist = "RANK" in os.environ
+    if use_dist:
+        dist.init_process_group("gloo")
+    B, E = args.batch, 256
+    g = torch.Generator().manual_seed(rank)
+    gathered = torch.empty(world * B, E) if use_dist else None
+
+    def step():
+        emb = torch.nn.functional.normalize(torch.randn(B, E, generator=g), dim=1)
+        if use_dist:
+            dist.all_gather_into_tensor(gathered, emb)
+        return emb
+
+    for _ in range(args.warmup):
+        step()
+    if use_dist:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        emb = step()
+    if use_dist:
+        dist.barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if use_dist:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        assert torch.equal(gathered[rank * B:(rank + 1) * B], emb)
+    if rank == 0:
+        print(json.dumps({"metric": "x-vectors/sec (4 s @ 16 kHz)", "value": world * B * args.steps / t.item(), "unit": "x-vectors/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": t.item() / args.steps * 1e3,
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "none", "data": "dry-run (CPU stand-in, no GPU work)",
+                          "config": {"workload": "dry run of the launch / gather / timing plumbing", "batch_per_gpu": B,
+                                     "parallelism": f"utterance-sharded x{world} (gloo)"}}), flush=True)
+    if use_dist:
+        dist.destroy_process_group()
 
 
 def main():
@@ -135,7 +248,14 @@ def main():
     ap.add_argument("--arch", default="halfresnet34", choices=["halfresnet34", "xvector"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
+    ap.add_argument("--dry-run", action="store_true", help="CPU/gloo stand-in of the loop (plumbing test, not a measurement)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # launched like the N = 1 command: start the ranks ourselves, as fresh child processes created before any GPU call
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
+    if args.dry_run:
+        return dry_run(args)
 
     import torch
     import torch.distributed as dist
@@ -169,7 +289,7 @@ def main():
 
     # Measurement plan: an event pair per kernel launch costs ~2 us of stream time (150 pairs per step = 4-6 % of the
     # step), so the per-class table comes from the LAST (up to 3) warmup steps with every class bracketed, and the timed
-    # region brackets only the dominant class -- the one the roofline object is about.
+    # region brackets only the two largest classes -- the ones the roofline object is about.
     per_class, focus, n_prof = None, None, 0
     n_prof_warm = 0 if args.no_profile else min(3, args.warmup)
     for i in range(args.warmup):
@@ -182,10 +302,10 @@ def main():
             prof_w = model.get_profile(reset=True)
             per_class = {k: round(v[0] / n_prof_warm, 4) for k, v in prof_w.items()}
             convs = {k: v for k, v in prof_w.items() if k in CONV_SHAPES}
-            focus = max(convs, key=lambda k: convs[k][0]) if convs else None
+            focus = sorted(convs, key=lambda k: -convs[k][0])[:2] if convs else None   # the two co-dominant classes
             n_prof = n_prof_warm
         if focus:
-            model.set_profile(True, slots=[focus])
+            model.set_profile(True, slots=focus)
         else:
             model.set_profile(True)          # no warmup to pick a class from: bracket everything in the timed region
         model.get_profile(reset=True)
@@ -220,14 +340,14 @@ def main():
                        "parallelism": f"utterance-sharded x{world}" + (" + RCCL all-gather of x-vectors" if use_dist else "")},
         }
         if not args.no_profile:
-            prof = model.get_profile(reset=True)   # timed region: the dominant class only (or all, see above)
-            r = roofline(prof, B, T, dtype) if args.arch == "halfresnet34" else None
+            prof = model.get_profile(reset=True)   # timed region: the two largest classes only (or all, see above)
+            r = roofline(prof, B, T, dtype, per_class) if args.arch == "halfresnet34" else None
             if r is not None:
                 if per_class is None:
                     per_class = {k: round(v[0] / args.steps, 4) for k, v in prof.items()}
                     r["per_class_source"] = "timed region, every class bracketed"
                 else:
-                    r["per_class_source"] = f"last {n_prof} warmup steps, every class bracketed; the timed region brackets {focus} only"
+                    r["per_class_source"] = f"last {n_prof} warmup steps, every class bracketed; the timed region brackets {' and '.join(focus)} only"
                 r["per_class_ms_per_step"] = per_class
             out["roofline"] = r
         if world == 1 and not args.no_cpu_baseline and args.arch == "halfresnet34":

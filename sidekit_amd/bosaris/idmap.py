@@ -5,6 +5,8 @@ import logging
 
 import numpy
 
+from . import _h5
+
 from ._sets import as_ids, member_mask, read_columns
 
 
@@ -17,9 +19,31 @@ class IdMap:
         self.rightids = numpy.empty(0, dtype="|O")
         self.start = numpy.empty(0, dtype="|O")
         self.stop = numpy.empty(0, dtype="|O")
-        if idmap_filename != '':
-            tmp = IdMap.read_txt(idmap_filename)
+        if idmap_filename != '':   # the reference reads HDF5 here (idmap.py:62-67); a text file is recognised by its first bytes
+            tmp = IdMap.read(idmap_filename) if _h5.is_hdf5(idmap_filename) else IdMap.read_txt(idmap_filename)
             self.leftids, self.rightids, self.start, self.stop = tmp.leftids, tmp.rightids, tmp.start, tmp.stop
+
+    def write(self, output_file_name):
+        """HDF5 form of ``idmap.py:84-116``: ``leftids`` / ``rightids`` byte strings, ``start`` / ``stop`` int32 (-1 = unset)."""
+        assert self.validate(), "Error: wrong IdMap format"
+        w = _h5.hdf5_lite.Writer()
+        w["leftids"] = self.leftids.astype('S')
+        w["rightids"] = self.rightids.astype('S')
+        w["start"] = _h5.bounds_to_file(self.start)
+        w["stop"] = _h5.bounds_to_file(self.stop)
+        w.save(output_file_name)
+
+    @staticmethod
+    def read(input_file_name):
+        """``idmap.py:283-310``."""
+        with _h5.hdf5_lite.File(input_file_name) as f:
+            idmap = IdMap()
+            idmap.leftids = _h5.ids_from_file(f["leftids"][()], 255)
+            idmap.rightids = _h5.ids_from_file(f["rightids"][()], 255)
+            idmap.start = _h5.bounds_from_file(f["start"][()])
+            idmap.stop = _h5.bounds_from_file(f["stop"][()])
+        assert idmap.validate(), "Error: wrong IdMap format"
+        return idmap
 
     def __repr__(self):
         return ('-' * 30 + '\nleft ids:' + repr(self.leftids) + '\nright ids:' + repr(self.rightids) + '\nseg start:'

@@ -4,6 +4,8 @@ import logging
 
 import numpy
 
+from . import _h5
+
 from ._sets import as_ids, member_mask, read_columns, sorted_difference
 from .ndx import Ndx
 
@@ -20,9 +22,31 @@ class Key:
             return
         if key_file_name is None:
             self._fill(numpy.asarray(models), numpy.asarray(testsegs), numpy.asarray(trials))
-        else:
-            tmp = Key.read_txt(key_file_name)
+        else:   # the reference reads HDF5 here (key.py:84-90); a text key is recognised by its first bytes
+            tmp = Key.read(key_file_name) if _h5.is_hdf5(key_file_name) else Key.read_txt(key_file_name)
             self.modelset, self.segset, self.tar, self.non = tmp.modelset, tmp.segset, tmp.tar, tmp.non
+
+    def write(self, output_file_name):
+        """HDF5 form of ``key.py:128-149``: ``trial_mask`` int8 = +1 target, -1 non-target, 0 no trial."""
+        assert self.validate(), "Error: wrong Key format"
+        w = _h5.hdf5_lite.Writer()
+        w["modelset"] = self.modelset.astype('S')
+        w["segset"] = self.segset.astype('S')
+        w["trial_mask"] = numpy.array(self.tar, dtype='int8') - numpy.array(self.non, dtype='int8')
+        w.save(output_file_name)
+
+    @staticmethod
+    def read(input_file_fame):
+        """``key.py:238-260``."""
+        with _h5.hdf5_lite.File(input_file_fame) as f:
+            key = Key(None, None, None, None)
+            key.modelset = _h5.ids_from_file(f["modelset"][()], 100)
+            key.segset = _h5.ids_from_file(f["segset"][()], 100)
+            trialmask = f["trial_mask"][()]
+            key.tar = (trialmask == 1)
+            key.non = (trialmask == -1)
+        assert key.validate(), "Error: wrong Key format"
+        return key
 
     def _fill(self, models, testsegs, trials):
         self.modelset = numpy.unique(models)

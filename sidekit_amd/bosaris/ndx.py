@@ -4,6 +4,8 @@ import logging
 
 import numpy
 
+from . import _h5
+
 from ._sets import as_ids, member_mask, read_columns, sorted_difference
 
 
@@ -29,9 +31,29 @@ class Ndx:
             self.segset = numpy.unique(testsegs)
             self.trialmask = _trial_matrix(models, testsegs, self.modelset, self.segset)
             assert self.validate(), "Wrong Ndx format"
-        else:
-            tmp = Ndx.read_txt(ndx_file_name)
+        else:   # the reference reads HDF5 here (ndx.py:85-90); a text trial list is recognised by its first bytes
+            tmp = Ndx.read(ndx_file_name) if _h5.is_hdf5(ndx_file_name) else Ndx.read_txt(ndx_file_name)
             self.modelset, self.segset, self.trialmask = tmp.modelset, tmp.segset, tmp.trialmask
+
+    def write(self, output_file_name):
+        """HDF5 form of ``ndx.py:92-112``: ``modelset`` / ``segset`` byte strings, ``trial_mask`` int8."""
+        assert self.validate(), "Error: wrong Ndx format"
+        w = _h5.hdf5_lite.Writer()
+        w["modelset"] = self.modelset.astype('S')
+        w["segset"] = self.segset.astype('S')
+        w["trial_mask"] = self.trialmask.astype('int8')
+        w.save(output_file_name)
+
+    @staticmethod
+    def read(input_file_name):
+        """``ndx.py:184-204``."""
+        with _h5.hdf5_lite.File(input_file_name) as f:
+            ndx = Ndx()
+            ndx.modelset = _h5.ids_from_file(f["modelset"][()], 100)
+            ndx.segset = _h5.ids_from_file(f["segset"][()], 100)
+            ndx.trialmask = f["trial_mask"][()].astype("bool")
+        assert ndx.validate(), "Error: wrong Ndx format"
+        return ndx
 
     def validate(self):
         ok = isinstance(self.modelset, numpy.ndarray) and isinstance(self.segset, numpy.ndarray)

@@ -4,6 +4,8 @@ import os
 
 import numpy
 
+from . import _h5
+
 from ._sets import as_ids, first_index, member_mask, read_columns, sorted_difference
 from .key import Key
 from .ndx import Ndx
@@ -17,9 +19,30 @@ class Scores:
         self.segset = numpy.empty(0, dtype="|O")
         self.scoremask = numpy.array([], dtype="bool")
         self.scoremat = numpy.array([])
-        if scores_file_name != '':
-            tmp = Scores.read_txt(scores_file_name)
+        if scores_file_name != '':   # the reference reads HDF5 here (scores.py:75-81); a text score file is recognised by its first bytes
+            tmp = Scores.read(scores_file_name) if _h5.is_hdf5(scores_file_name) else Scores.read_txt(scores_file_name)
             self.modelset, self.segset, self.scoremask, self.scoremat = tmp.modelset, tmp.segset, tmp.scoremask, tmp.scoremat
+
+    def write(self, output_file_name):
+        """HDF5 form of ``scores.py:94-116``: ``score_mask`` int8, ``scores`` in the matrix's own float type."""
+        w = _h5.hdf5_lite.Writer()
+        w["modelset"] = self.modelset.astype('S')
+        w["segset"] = self.segset.astype('S')
+        w["score_mask"] = self.scoremask.astype('int8')
+        w["scores"] = self.scoremat
+        w.save(output_file_name)
+
+    @staticmethod
+    def read(input_file_name):
+        """``scores.py:316-341``."""
+        with _h5.hdf5_lite.File(input_file_name) as f:
+            scores = Scores()
+            scores.modelset = _h5.ids_from_file(f["modelset"][()], 100)
+            scores.segset = _h5.ids_from_file(f["segset"][()], 100)
+            scores.scoremask = f["score_mask"][()].astype('bool')
+            scores.scoremat = f["scores"][()]
+        assert scores.validate(), "Error: wrong Scores format"
+        return scores
 
     def validate(self):
         ok = self.scoremat.shape == self.scoremask.shape

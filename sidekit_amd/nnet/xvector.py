@@ -497,8 +497,8 @@ def test_metrics(model, device, model_opts, data_opts, train_opts, as_norm=True)
     cosine, the trials of the Ndx, EER from ``rocch`` / ``rocch2eer``; with ``as_norm`` also the EER of the adaptive
     s-normalised scores (cohort = rows of ``after_speaker_embedding.weight``), returned as ``(eer, norm_eer)``.
 
-    ``data_opts["test"]["ndx"]`` / ``["key"]`` may be ``Ndx`` / ``Key`` objects or file names (HDF5 needs h5py, text
-    files go through ``read_txt``).  The N x N cosine matrix and the normalisation run on the GPU."""
+    ``data_opts["test"]["ndx"]`` / ``["key"]`` may be ``Ndx`` / ``Key`` objects or file names (HDF5 as the reference writes
+    it, or text trial lists).  The N x N cosine matrix and the normalisation run on the GPU."""
     from ..bosaris import Key, Ndx
     from ..bosaris.detplot import rocch, rocch2eer
     from ..iv_scoring import cosine_matrix

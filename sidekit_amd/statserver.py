@@ -4,16 +4,19 @@ Mirrors the attributes (``modelset, segset, start, stop, stat0, stat1``; ``stats
 the ~10 methods the x-vector scoring path calls: ``validate`` (:318-336), ``align_models`` /
 ``align_segments`` (:656-684), ``norm_stat1`` / ``rotate_stat1`` / ``center_stat1`` / ``whiten_stat1``
 (:797-817,852-896), ``get_mean_stat1`` (:789-795), ``mean_stat_per_model`` (:1357-1374).  GMM statistics,
-MAP, i-vector extraction and HDF5 I/O are out of scope.  Values are float64
+MAP and i-vector extraction are out of scope; ``read`` / ``write`` (:392-489) exchange HDF5 files with the
+reference through ``sidekit_amd.hdf5_lite``.  Values are float64
 (``STAT_TYPE``, ``sidekit/__init__.py:59``); the alignments use hashed lookups instead of per-id scans.
 """
 import copy
 import logging
+import os
 
 import numpy
 import scipy.linalg
 
-from .bosaris import IdMap
+from . import hdf5_lite
+from .bosaris import IdMap, _h5
 from .bosaris._sets import first_index
 
 STAT_TYPE = numpy.float64
@@ -35,7 +38,52 @@ class StatServer:
             self.stat0 = numpy.zeros((self.segset.shape[0], distrib_nb), dtype=STAT_TYPE)
             self.stat1 = numpy.zeros((self.segset.shape[0], distrib_nb * feature_size), dtype=STAT_TYPE)
             return
-        raise NotImplementedError("reading a StatServer from an HDF5 file is out of scope (SURVEY 8f rank 3)")
+        if isinstance(statserver_file_name, str):   # statserver.py:237-245: an HDF5 file written by StatServer.write
+            tmp = StatServer.read(statserver_file_name)
+            self.modelset, self.segset, self.start, self.stop = tmp.modelset, tmp.segset, tmp.start, tmp.stop
+            self.stat0, self.stat1 = tmp.stat0, tmp.stat1
+            return
+        raise TypeError("StatServer(): expected a file name or an IdMap")
+
+    @staticmethod
+    def read(statserver_file_name, prefix=''):
+        """``statserver.py:392-424``: the six datasets ``<prefix>modelset, segset, start, stop, stat0, stat1``; identifiers come
+        back as unicode, ``start`` / ``stop`` as object arrays with ``None`` where the file holds -1, statistics as float64."""
+        with hdf5_lite.File(statserver_file_name) as f:
+            statserver = StatServer()
+            statserver.modelset = _h5.ids_from_file(f[prefix + "modelset"][()])
+            statserver.segset = _h5.ids_from_file(f[prefix + "segset"][()])
+            statserver.start = _h5.bounds_from_file(f[prefix + "start"][()])
+            statserver.stop = _h5.bounds_from_file(f[prefix + "stop"][()])
+            statserver.stat0 = f[prefix + "stat0"][()].astype(dtype=STAT_TYPE)
+            statserver.stat1 = f[prefix + "stat1"][()].astype(dtype=STAT_TYPE)
+        assert statserver.validate(), "Error: wrong StatServer format"
+        return statserver
+
+    def write(self, output_file_name, prefix='', mode='w'):
+        """``statserver.py:427-489``: float32 statistics, byte-string identifiers, int32 ``start`` / ``stop`` (-1 = unset), every
+        dataset gzip + Fletcher-32 with unlimited rows.  ``mode='a'`` on a file that already holds ``<prefix>`` datasets appends
+        the rows to them (the reference resizes in place; here the file is rewritten -- other groups of the file are kept);
+        ``mode='a'`` with a new prefix adds the six datasets beside what the file holds."""
+        assert self.validate(), "Error: wrong StatServer format"
+        new = {"modelset": self.modelset.astype('S'), "segset": self.segset.astype('S'), "stat0": self.stat0.astype(numpy.float32),
+               "stat1": self.stat1.astype(numpy.float32), "start": _h5.bounds_to_file(self.start), "stop": _h5.bounds_to_file(self.stop)}
+        existing = {}
+        if mode != 'w' and os.path.exists(output_file_name):
+            existing = hdf5_lite.read_all(output_file_name)
+        w = hdf5_lite.Writer()
+        for path, arr in existing.items():
+            if not (path.startswith(prefix) and path[len(prefix):] in new):
+                w[path] = arr
+        for name, arr in new.items():
+            old = existing.get(prefix + name)
+            if old is not None:
+                if name in ("modelset", "segset"):   # widen the byte strings to the longer of the two
+                    width = max(old.dtype.itemsize, arr.dtype.itemsize)
+                    old, arr = old.astype(f"S{width}"), arr.astype(f"S{width}")
+                arr = numpy.concatenate((old, arr.astype(old.dtype, copy=False)), axis=0)
+            w[prefix + name] = arr
+        w.save(output_file_name)
 
     def __repr__(self):
         line = '-' * 30 + '\n'

@@ -13,7 +13,7 @@ The torchaudio stand-in's MelSpectrogram / MFCC compute with oracle/frontend.py 
 restatement of torchaudio 0.8.2), so every *network* fixture is cut at the features seam, where no
 stand-in arithmetic is involved; wav-level fixtures are labelled `unpinned_frontend`.
 
-Usage:  PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py [halfresnet34] [tdnn] [scoring] [asnorm]
+Usage:  PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py [halfresnet34] [tdnn] [scoring] [asnorm] [examples]
 """
 import importlib
 import os
@@ -340,10 +340,46 @@ def asnorm_fixtures(mods, out):
     print("asnorm.npz", s.shape, s.dtype)
 
 
+def examples_fixtures(mods, out):
+    """Fixture set (ii) of SURVEY 8(c) / BASELINE config 1: the reference HalfResNet34 (F1' pooling shape, seeded checkpoint) run on
+    the three ``egs/examples_decode`` wavs exactly as ``extract_xvectors.py:143-147`` feeds them (whole file, batch 1) and on
+    their first 64000 samples.  The wavs travel as PCM16 arrays (the GPU box has no reference tree).  The reference front-end
+    is the torchaudio stand-in (= oracle/frontend.py), so ``emb_*`` is at once the features-seam target (oracle features ->
+    reference network: pinned) and the wav-level target of the build's own front-end (labelled ``unpinned_frontend``)."""
+    import scipy.io.wavfile
+    xv, pooling = mods["sidekit.nnet.xvector"], mods["sidekit.nnet.pooling"]
+    n_spk, seed = 16, 1234
+    ref = xv.Xtractor(n_spk, model_archi="halfresnet34", loss="aam")
+    ref.stat_pooling = pooling.AttentivePooling(256, 10, global_context=True)  # SURVEY F1'
+    sd = seeded_state_dict("halfresnet34", n_spk, seed=seed)
+    ref.load_state_dict(sd, strict=True)
+    ref.eval()
+    fx = {"n_spk": n_spk, "seed": seed, "sample_rate": 16000}
+    names = []
+    with open(os.path.join(REF, "egs/examples_decode/wav_example.scp")) as f:
+        for line in f:
+            key, wav = line.split()
+            names.append(key)
+            sr, pcm = scipy.io.wavfile.read(os.path.join(REF, "egs/examples_decode", wav))
+            assert sr == 16000 and pcm.dtype == numpy.int16 and pcm.ndim == 1
+            fx[f"pcm16_{key}"] = pcm
+            x = torch.from_numpy(pcm.astype(numpy.float32) / 32768.0)
+            with torch.no_grad():
+                for tag, sig in (("full", x), ("first4s", x[:64000])):
+                    _, emb = ref(sig, is_eval=True)
+                    fx[f"emb_{tag}_{key}_unpinned_frontend"] = emb.numpy()
+                    feats = ofe.melspec_frontend(sig.unsqueeze(0))
+                    o_logits, o_emb = oxv.halfresnet34_from_feats(feats, sd)
+                    assert torch.allclose(o_emb, emb, atol=2e-6), (key, tag, (o_emb - emb).abs().max())
+    fx["keys"] = numpy.array(names)
+    numpy.savez_compressed(os.path.join(out, "examples_decode.npz"), **fx)
+    print("examples_decode.npz", {k: getattr(v, "shape", v) for k, v in fx.items()})
+
+
 def main():
     mods = import_reference()
     torch.set_num_threads(8)
-    only = sys.argv[1:] or ["halfresnet34", "tdnn", "scoring", "asnorm"]
+    only = sys.argv[1:] or ["halfresnet34", "tdnn", "scoring", "asnorm", "examples"]
     if "halfresnet34" in only:
         halfresnet_fixtures(mods, HERE)
     if "tdnn" in only:
@@ -352,6 +388,8 @@ def main():
         scoring_fixtures(mods, HERE)
     if "asnorm" in only:
         asnorm_fixtures(mods, HERE)
+    if "examples" in only:
+        examples_fixtures(mods, HERE)
 
 
 if __name__ == "__main__":

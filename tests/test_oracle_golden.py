@@ -145,3 +145,23 @@ def test_frontend_building_blocks():
 def test_asnorm_oracle_matches_reference(golden_dir):
     fx = numpy.load(os.path.join(golden_dir, "asnorm.npz"))
     numpy.testing.assert_allclose(osc.asnorm(fx["enrol"], fx["cohort"]), fx["snorm"], atol=1e-6)
+
+
+def test_oracle_reproduces_examples_decode_embeddings(golden_dir):
+    """Fixture set (ii): the reference on the three egs/examples_decode wavs (whole files and first 4 s)."""
+    import os
+    import numpy
+    import torch
+    from oracle import xvector as oxv
+    from sidekit_amd.nnet.weights import seeded_state_dict
+    ex = numpy.load(os.path.join(golden_dir, "examples_decode.npz"))
+    sd = seeded_state_dict("halfresnet34", int(ex["n_spk"]), seed=int(ex["seed"]))
+    assert [int(ex[f"pcm16_{k}"].shape[0]) for k in ex["keys"]] == [93680, 199760, 158400]     # SURVEY 8d config 1
+    torch.set_num_threads(8)
+    for k in [str(k) for k in ex["keys"]][:2]:                       # two files keep the CPU suite short
+        x = torch.from_numpy(ex[f"pcm16_{k}"].astype(numpy.float32) / 32768.0)
+        with torch.no_grad():
+            _, full = oxv.halfresnet34_forward(x.unsqueeze(0), sd)
+            _, first = oxv.halfresnet34_forward(x[:64000].unsqueeze(0), sd)
+        assert torch.allclose(full, torch.from_numpy(ex[f"emb_full_{k}_unpinned_frontend"]), atol=2e-6)
+        assert torch.allclose(first, torch.from_numpy(ex[f"emb_first4s_{k}_unpinned_frontend"]), atol=2e-6)
