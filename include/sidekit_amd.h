@@ -134,6 +134,16 @@ int sc_cosine(const float* d_E, int32_t Ne, const float* d_T, int32_t Nt, int32_
 int sc_plda_fast(const double* d_E, int32_t Ne, const double* d_T, int32_t Nt, int32_t D, const double* d_Phi,
                  const double* d_Psi, double cst, double scaling, double* d_out, void* stream);
 
+/* All-pairs cosine scoring without the score matrix (100k x 100k trials = 40 GB of float32): the scores of
+ * sc_cosine are classified target (labels_e[i] == labels_t[j]) / non-target and counted into two histograms of `nbins`
+ * (= 8192) equal bins over [lo, hi) (out-of-range scores land in the end bins); self_offset >= 0 drops the trials
+ * j == i + self_offset, i.e. the self-trials when E is rows [self_offset, self_offset + Ne) of T (a set, or one rank's row
+ * shard of it, scored against itself: the trials sidekit/nnet/xvector.py:240-262 masks out through its Ndx); < 0 keeps all.
+ * The EER of the binned scores follows on the host (sidekit_amd.bosaris.detplot.eer_from_histograms). */
+int sc_cosine_hist(const float* d_E, int32_t Ne, const float* d_T, int32_t Nt, int32_t D, const int32_t* d_labels_e,
+                   const int32_t* d_labels_t, int32_t self_offset, float lo, float hi, int32_t nbins, uint64_t* d_hist_tar,
+                   uint64_t* d_hist_non, void* stream);
+
 /* Speaker-mean enrolment + cosine over a listed trial set, sidekit/bin/compute_spk_cosine.py:18-26:
  * out[k] = <E[enr_idx[k]], T[tst_idx[k]]> / (|E| |T|), float32 in, float64 maths. */
 int sc_cosine_trials(const float* d_E, const float* d_T, int32_t D, const int32_t* d_enr_idx, const int32_t* d_tst_idx,

@@ -3,11 +3,20 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 -m sidekit_amd.bin.shard_extract_score \\
         --utterances 100000 --batch 256 --seconds 4
 
-Every rank (one process per GPU) extracts the contiguous utterance range ``shard_range(n, rank, world)`` from
-synthetic waveforms (batch k of rank r is generated on the device with seed ``1000 + r * n_batches + k``), the
-``(N_r, 256)`` x-vector blocks are all-gathered over RCCL (the only exchange step of the path), then a synthetic
-trial matrix is scored with cosine / fast PLDA sharded by enrolment rows and rank 0 prints the EER and timings as
-one JSON line.  Without ``torch.distributed.run`` it runs as a single rank.
+Every rank (one process per GPU) extracts the contiguous utterance range ``shard_range(n, rank, world)`` of a synthetic
+corpus, the ``(N_r, 256)`` x-vector blocks are all-gathered over RCCL (the only exchange step of the path), and the trial
+set OF THOSE x-vectors is scored: the first ``--trials`` utterances are the enrolment side, the next ``--trials`` the test side
+(full trial mask, target = same synthetic speaker), the remainder trains the PLDA parameters.  Scoring is sharded by enrolment
+rows and stays on the device end to end: cosine (f32 MFMA) and fast PLDA (f64 MFMA) row blocks are gathered on rank 0, which
+prints EERs and timings as one JSON line.  ``--all-pairs`` adds the matrix-free path: every pair of the corpus scored into
+target / non-target histograms, the per-rank counts summed with one all-reduce.  Without ``torch.distributed.run`` it runs
+as a single rank.
+
+The corpus: speaker s is a fixed set of sinusoids (``RandomState(0)``), an utterance adds per-utterance phases, amplitude
+jitter and white noise (batch k of rank r is generated on the device with seed ``1000 + r * n_batches + k``) -- enough
+structure for the randomly initialised extractor to separate speakers with a non-trivial EER.  The PLDA parameters are a
+moment estimate (between / within speaker covariance of the training x-vectors); PLDA *training* proper
+(``sidekit/factor_analyser.py:830-932``) is out of scope, the parameters are inputs to the scoring path.
 """
 import argparse
 import json
@@ -19,9 +28,44 @@ import torch
 import torch.distributed as dist
 
 from .. import iv_scoring
-from ..bosaris import rocch, rocch2eer
+from ..bosaris import eer_from_histograms, rocch, rocch2eer
 from ..nnet import Xtractor
 from ..sharding import gather_xvectors, score_sharded, shard_range
+
+N_TONES = 6
+
+
+def speaker_table(n_spk):
+    rs = numpy.random.RandomState(0)
+    return rs.uniform(120.0, 7000.0, (n_spk, N_TONES)), rs.uniform(0.3, 1.0, (n_spk, N_TONES))
+
+
+def synth_batch(spk, freqs, amps, L, noise, gen, dev):
+    """(B,) speaker ids -> (B, L) float32 waveforms on `dev`."""
+    B = spk.shape[0]
+    t = torch.arange(L, device=dev, dtype=torch.float32) / 16000.0
+    f = torch.as_tensor(freqs[spk], dtype=torch.float32, device=dev)               # (B, tones)
+    a = torch.as_tensor(amps[spk], dtype=torch.float32, device=dev) * (0.7 + 0.6 * torch.rand(B, N_TONES, device=dev, generator=gen))
+    ph = 6.2831853 * torch.rand(B, N_TONES, device=dev, generator=gen)
+    x = torch.zeros(B, L, device=dev)
+    for k in range(N_TONES):
+        x += a[:, k:k + 1] * torch.sin(6.2831853 * f[:, k:k + 1] * t[None, :] + ph[:, k:k + 1])
+    return 0.05 * x + noise * torch.randn(B, L, device=dev, generator=gen)
+
+
+def plda_moments(X, labels, rank):
+    """Two-covariance moment estimate -> (mu, F, Sigma) as ``fast_PLDA_scoring`` takes them (float64 numpy)."""
+    X = numpy.asarray(X, dtype=numpy.float64)
+    mu = X.mean(axis=0)
+    ids, inv = numpy.unique(labels, return_inverse=True)
+    means = numpy.stack([X[inv == i].mean(axis=0) for i in range(ids.shape[0])])
+    W = numpy.cov((X - means[inv]).T, bias=True)
+    Bc = numpy.cov((means - mu).T, bias=True)
+    w, V = numpy.linalg.eigh(Bc)
+    top = numpy.argsort(w)[::-1][:rank]
+    F = V[:, top] * numpy.sqrt(numpy.maximum(w[top], 1e-12))
+    Sigma = W + 1e-4 * numpy.trace(W) / W.shape[0] * numpy.eye(W.shape[0])
+    return mu, F, Sigma
 
 
 def main(argv=None):
@@ -31,7 +75,12 @@ def main(argv=None):
     ap.add_argument("--seconds", type=float, default=4.0)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--trials", type=int, default=1000, help="enrolment models = test segments = this many (full trial mask)")
+    ap.add_argument("--speakers", type=int, default=250)
+    ap.add_argument("--noise", type=float, default=0.12, help="white-noise level of the synthetic utterances (sets the EER)")
+    ap.add_argument("--plda-rank", type=int, default=128)
+    ap.add_argument("--all-pairs", action="store_true", help="also score every pair of the corpus into histograms (no N x N matrix)")
     args = ap.parse_args(argv)
+    assert args.utterances >= 2 * args.trials + 2 * args.speakers, "need utterances for enrolment, test and PLDA training"
     rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -41,41 +90,64 @@ def main(argv=None):
     model = Xtractor(7205, model_archi="halfresnet34", loss="aam", seed=1234).to(dev).eval()
     model.compute_dtype = args.dtype
     L = int(args.seconds * 16000)
-    start, stop = shard_range(args.utterances, rank, world)
+    N = args.utterances
+    labels = numpy.random.RandomState(1).randint(0, args.speakers, N).astype(numpy.int32)     # speaker of every utterance
+    freqs, amps = speaker_table(args.speakers)
+    start, stop = shard_range(N, rank, world)
     n_batches = (stop - start + args.batch - 1) // args.batch
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     blocks = []
     for k in range(n_batches):
-        b = min(args.batch, stop - start - k * args.batch)
+        lo = start + k * args.batch
+        hi = min(lo + args.batch, stop)
         g = torch.Generator(device=dev).manual_seed(1000 + rank * n_batches + k)
-        wav = 0.1 * torch.randn(b, L, device=dev, generator=g)
+        wav = synth_batch(labels[lo:hi], freqs, amps, L, args.noise, g, dev)
         blocks.append(model(wav, is_eval=True)[1])
     local_xv = torch.cat(blocks) if blocks else torch.empty(0, 256, device=dev)
     torch.cuda.synchronize(dev)
     t_extract = time.perf_counter() - t0
     t0 = time.perf_counter()
-    xv = gather_xvectors(local_xv)                      # (utterances, 256) on every rank
+    xv = gather_xvectors(local_xv)                      # (utterances, 256) on every rank, still on the device
     torch.cuda.synchronize(dev)
     t_gather = time.perf_counter() - t0
-    assert xv.shape == (args.utterances, 256)
-    # scoring leg: synthetic speakers (config 5 recipe), enrolment rows sharded over the ranks
-    rs = numpy.random.RandomState(0)
-    n_spk, D, N = 250, 256, args.trials
-    c = rs.randn(n_spk, D)
-    spk_e, spk_t = rs.randint(0, n_spk, N), rs.randint(0, n_spk, N)
-    norm = lambda x: x / numpy.linalg.norm(x, axis=1, keepdims=True)
-    E, T = norm(c[spk_e] + 1.8 * rs.randn(N, D)), norm(c[spk_t] + 1.8 * rs.randn(N, D))
+    assert xv.shape == (N, 256) and xv.is_cuda
+    # ---- the gathered x-vectors' own trial set: enrol [0, n), test [n, 2n), PLDA training on the rest
+    n = args.trials
+    E, T, train = xv[:n], xv[n:2 * n], xv[2 * n:]
+    tar = labels[:n, None] == labels[None, n:2 * n]
     t0 = time.perf_counter()
-    rows = score_sharded(lambda a, b: torch.from_numpy(iv_scoring.cosine_matrix(E[a:b], T, dev)).to(dev), N)
-    t_score = time.perf_counter() - t0
+    cos_rows = score_sharded(lambda a, b: iv_scoring.cosine_matrix_device(E[a:b], T, dev), n)   # rank 0 gets (n, n), device resident
+    torch.cuda.synchronize(dev)
+    t_cos = time.perf_counter() - t0
+    mu, F, Sigma = plda_moments(train.cpu().numpy(), labels[2 * n:], args.plda_rank)      # identical on every rank (same gathered data)
+    Phi, Psi, cst = iv_scoring.plda_parameters(mu, F, Sigma)
+    mu_d = torch.as_tensor(mu, device=dev)
+    Ec, Tc = E.double() - mu_d, T.double() - mu_d                                        # center_stat1 (statserver.py:810-817)
+    t0 = time.perf_counter()
+    plda_rows = score_sharded(lambda a, b: iv_scoring.plda_matrix_device(Ec[a:b], Tc, Phi, Psi, cst, 1.0, dev), n)
+    torch.cuda.synchronize(dev)
+    t_plda = time.perf_counter() - t0
+    out = {"ranks": world, "utterances": N, "x_vectors_per_s": N / t_extract, "extract_s": t_extract, "all_gather_s": t_gather,
+           "trials": n * n, "cosine_score_s": t_cos, "plda_score_s": t_plda, "dtype": args.dtype}
+    if args.all_pairs:
+        # matrix-free: rank r counts the pairs (i, j), i in its enrolment-row shard, j over the whole corpus, i != j
+        a, b = shard_range(N, rank, world)
+        lab_d = torch.as_tensor(labels, device=dev)
+        t0 = time.perf_counter()
+        ht, hn = iv_scoring.cosine_histograms(xv[a:b], xv, lab_d[a:b], lab_d, self_offset=a, device=dev)
+        torch.cuda.synchronize(dev)
+        counts = torch.as_tensor(numpy.stack([ht, hn]).astype(numpy.int64), device=dev)
+        if dist.is_initialized():
+            dist.all_reduce(counts)
+        t_hist = time.perf_counter() - t0
+        counts = counts.cpu().numpy()
+        out.update(all_pairs=int(counts.sum()), all_pairs_s=t_hist, all_pairs_eer=float(eer_from_histograms(counts[0], counts[1])))
     if rank == 0:
-        s = rows.cpu().numpy()
-        tar = spk_e[:, None] == spk_t[None, :]
-        eer = rocch2eer(*rocch(s[tar].astype(float), s[~tar].astype(float)))
-        print(json.dumps({"ranks": world, "utterances": args.utterances, "x_vectors_per_s": args.utterances / t_extract,
-                          "extract_s": t_extract, "all_gather_s": t_gather, "cosine_trials": N * N, "score_s": t_score, "eer": eer,
-                          "dtype": args.dtype}), flush=True)
+        for name, rows in (("cosine", cos_rows), ("plda", plda_rows)):
+            s = rows.cpu().numpy().astype(float)
+            out[f"{name}_eer"] = float(rocch2eer(*rocch(s[tar], s[~tar])))
+        print(json.dumps(out), flush=True)
     if dist.is_initialized():
         dist.destroy_process_group()
 

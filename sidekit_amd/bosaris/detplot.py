@@ -64,6 +64,38 @@ def rocch2eer(pmiss, pfa):
     return max(0, crossing.max())
 
 
+def rocch_from_histograms(hist_tar, hist_non):
+    """ROC convex hull vertices ``(pmiss, pfa)`` of scores known only as target / non-target counts per ascending score bin
+    (``iv_scoring.cosine_histograms``): the bins are tied-score groups with multiplicities, so the hull is that of
+    ``rocch`` on the binned scores -- a weighted pool-adjacent-violators fit of the per-bin target fraction."""
+    ht = numpy.asarray(hist_tar, dtype=numpy.float64)
+    hn = numpy.asarray(hist_non, dtype=numpy.float64)
+    keep = (ht + hn) > 0
+    ht, hn = ht[keep], hn[keep]
+    n_tar, n_non = ht.sum(), hn.sum()
+    assert n_tar > 0 and n_non > 0, "both histograms must hold trials"
+    # weighted PAV (non-decreasing): blocks of (targets, total) merged while a block's fraction is not above its predecessor's
+    bt, bw = [], []
+    for t, w in zip(ht, ht + hn):
+        bt.append(t)
+        bw.append(w)
+        while len(bt) > 1 and bt[-2] * bw[-1] >= bt[-1] * bw[-2]:      # frac[-2] >= frac[-1], without dividing
+            t2, w2 = bt.pop(), bw.pop()
+            bt[-1] += t2
+            bw[-1] += w2
+    bt, bw = numpy.array(bt), numpy.array(bw)
+    left_tar = numpy.concatenate(([0.0], numpy.cumsum(bt)))             # targets at or below each block edge = misses
+    left_all = numpy.concatenate(([0.0], numpy.cumsum(bw)))
+    pmiss = left_tar / n_tar
+    pfa = ((n_tar + n_non) - left_all - (n_tar - left_tar)) / n_non      # non-targets above the edge = false alarms
+    return pmiss, pfa
+
+
+def eer_from_histograms(hist_tar, hist_non):
+    """Equal error rate (ROCCH) of binned scores: ``rocch2eer(*rocch_from_histograms(...))``."""
+    return rocch2eer(*rocch_from_histograms(hist_tar, hist_non))
+
+
 def sigmoid(log_odds):
     return 1 / (1 + numpy.exp(-log_odds))
 

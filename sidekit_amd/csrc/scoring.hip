@@ -3,60 +3,146 @@
 //
 // cosine is one f32 MFMA GEMM over the already normalised rows.  PLDA keeps the reference's
 // float64 arithmetic end to end: the 256x256 algebra (Phi, Psi, constant) stays on the host, the
-// N^2 part runs here as a tiled f64 FMA GEMM (C = A . B^T) whose epilogue adds the two quadratic
-// terms and the constant, so the (Ne x Nt) matrix is written exactly once.
+// N^2 part runs here as an f64 MFMA GEMM (C = A . B^T, v_mfma_f64_16x16x4_f64) whose epilogue adds
+// the two quadratic terms and the constant, so the (Ne x Nt) matrix is written exactly once.  For
+// trial sets too large to materialise, sc_cosine_hist counts target / non-target scores into
+// histograms straight from the accumulators.
 #include "../../include/sidekit_amd.h"
 #include "kernels.h"
 
 namespace sk {
 
-constexpr int DT = 64, DK = 16;
+typedef double f64x4 __attribute__((ext_vector_type(4)));
 
-// C[m][n] = alpha * (sum_k A[m][k] Bop(k,n) + rowterm[m] + colterm[n] + cst)
+constexpr int DT = 64, DK = 16, DLD = DK + 1;   // 64 x 64 output tile per workgroup, 16-deep k-tiles, LDS rows padded by one double
+
+// C[m][n] = alpha * (sum_k A[m][k] Bop(k,n) + rowterm[m] + colterm[n] + cst), float64 end to end on the matrix cores:
+// v_mfma_f64_16x16x4_f64 (A: lane l holds A[l & 15][l >> 4], B: B[l >> 4][l & 15], D: four doubles per lane at
+// row (l >> 4) + 4 * reg, col l & 15 -- the f64 map, which differs from the f32 one).  Four waves, each a 32 x 32 quadrant = 2 x 2
+// MFMA tiles; operands staged through LDS as [row][k] with a 17-double row stride, which makes the ds_read_b64 fragment reads
+// (16 rows x 2 k per half-wave) hit 32 different bank pairs.
 //   B_KN = false: B is [N][K] (C = A . B^T);  B_KN = true: B is [K][N] (C = A . B)
 template <bool B_KN>
 __global__ __launch_bounds__(256) void dgemm_kernel(const double* __restrict__ A, const double* __restrict__ B, double* __restrict__ C,
                                                        int M, int N, int K, const double* __restrict__ rowterm,
                                                        const double* __restrict__ colterm, double cst, double alpha) {
-  __shared__ double As[DK][DT + 1];
-  __shared__ double Bs[DK][DT + 1];
-  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+  __shared__ __attribute__((aligned(16))) double As[DT * DLD];
+  __shared__ __attribute__((aligned(16))) double Bs[DT * DLD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, lr = lane & 15, lk = lane >> 4;
   const int m0 = blockIdx.y * DT, n0 = blockIdx.x * DT;
-  double acc[4][4];
+  f64x4 acc[2][2];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
+    for (int j = 0; j < 2; ++j) acc[i][j] = f64x4{0.0, 0.0, 0.0, 0.0};
   for (int k0 = 0; k0 < K; k0 += DK) {
+    // stage: 64 rows x 16 k per operand, consecutive threads along the contiguous dimension of each source
     for (int i = tid; i < DT * DK; i += 256) {
-      const int row = i / DK, kk = i % DK;
-      const int m = m0 + row, n = n0 + row, k = k0 + kk;
-      As[kk][row] = (m < M && k < K) ? A[(long)m * K + k] : 0.0;
-      Bs[kk][row] = (n < N && k < K) ? (B_KN ? B[(long)k * N + n] : B[(long)n * K + k]) : 0.0;
+      const int row = i / DK, kk = i % DK, m = m0 + row, k = k0 + kk;
+      As[row * DLD + kk] = (m < M && k < K) ? A[(long)m * K + k] : 0.0;
+      if constexpr (!B_KN) {
+        const int n = n0 + row;
+        Bs[row * DLD + kk] = (n < N && k < K) ? B[(long)n * K + k] : 0.0;
+      }
+    }
+    if constexpr (B_KN) {
+      for (int i = tid; i < DT * DK; i += 256) {
+        const int kk = i / DT, col = i % DT, n = n0 + col, k = k0 + kk;
+        Bs[col * DLD + kk] = (n < N && k < K) ? B[(long)k * N + n] : 0.0;
+      }
     }
     __syncthreads();
 #pragma unroll
-    for (int kk = 0; kk < DK; ++kk) {
-      double a[4], b[4];
+    for (int kk = 0; kk < DK; kk += 4) {
+      double a[2], b[2];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { a[i] = As[kk][ty + 16 * i]; b[i] = Bs[kk][tx + 16 * i]; }
+      for (int i = 0; i < 2; ++i) {
+        a[i] = As[(wm * 32 + i * 16 + lr) * DLD + kk + lk];
+        b[i] = Bs[(wn * 32 + i * 16 + lr) * DLD + kk + lk];
+      }
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = fma(a[i], b[j], acc[i][j]);
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
     }
     __syncthreads();
   }
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = m0 + ty + 16 * i;
-    if (m >= M) continue;
-    const double rt = rowterm ? rowterm[m] : 0.0;
+  for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n = n0 + tx + 16 * j;
-      if (n < N) C[(long)m * N + n] = alpha * (acc[i][j] + rt + (colterm ? colterm[n] : 0.0) + cst);
+    for (int q = 0; q < 4; ++q) {
+      const int m = m0 + wm * 32 + i * 16 + lk + 4 * q;
+      if (m >= M) continue;
+      const double rt = rowterm ? rowterm[m] : 0.0;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn * 32 + j * 16 + lr;
+        if (n < N) C[(long)m * N + n] = alpha * (acc[i][j][q] + rt + (colterm ? colterm[n] : 0.0) + cst);
+      }
     }
+}
+
+// ---- all-pairs cosine scoring WITHOUT the score matrix (100k x 100k trials are 40 GB of float32) ---------------------
+// Persistent workgroups walk the 64 x 64 tiles of E . T^T (f32 MFMA, the arithmetic of sc_cosine), classify every score as
+// target / non-target from the two label vectors and count it into a private LDS histogram pair; the histograms are added to
+// the global 64-bit counters once, at the end.  EER / ROCCH then come from the counts (bosaris.detplot.eer_from_histograms).
+constexpr int HB = 8192;   // bins per histogram: 2 x 32 KB of LDS per workgroup, one persistent workgroup per CU
+
+__global__ __launch_bounds__(256, 1) void cosine_hist_kernel(const float* __restrict__ E, int Ne, const float* __restrict__ T, int Nt, int D,
+                                                             const int* __restrict__ le, const int* __restrict__ lt, int self_offset,
+                                                             float lo, float inv_width, unsigned long long* __restrict__ hist_tar,
+                                                             unsigned long long* __restrict__ hist_non) {
+  __shared__ unsigned hist[2 * HB];
+  __shared__ __attribute__((aligned(16))) float Es[64 * 36];
+  __shared__ __attribute__((aligned(16))) float Ts[64 * 36];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5, wm = wave >> 1, wn = wave & 1;
+  for (int i = tid; i < 2 * HB; i += 256) hist[i] = 0u;
+  const long tiles_n = (Nt + 63) / 64, ntiles = (long)((Ne + 63) / 64) * tiles_n;
+  const int srow = tid >> 3, sk4 = (tid & 7) * 4;
+  for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int m0 = (int)(tile / tiles_n) * 64, n0 = (int)(tile % tiles_n) * 64;
+    f32x16 acc;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+    for (int k0 = 0; k0 < D; k0 += 32) {
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int row = srow + q * 32, k = k0 + sk4;
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(&Es[row * 36 + sk4]) = (m0 + row < Ne && k < D) ? *reinterpret_cast<const float4*>(E + (long)(m0 + row) * D + k) : z;
+        *reinterpret_cast<float4*>(&Ts[row * 36 + sk4]) = (n0 + row < Nt && k < D) ? *reinterpret_cast<const float4*>(T + (long)(n0 + row) * D + k) : z;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int kk = 0; kk < 32; kk += 8) {
+        const float4 a = *reinterpret_cast<const float4*>(&Es[(wm * 32 + r) * 36 + kk + 4 * h]);
+        const float4 b = *reinterpret_cast<const float4*>(&Ts[(wn * 32 + r) * 36 + kk + 4 * h]);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+      }
+    }
+    const int n = n0 + wn * 32 + r;
+    if (n < Nt) {
+      const int ln = lt[n];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int m = m0 + wm * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+        if (m >= Ne || (self_offset >= 0 && m + self_offset == n)) continue;
+        int bin = (int)floorf((acc[q] - lo) * inv_width);
+        bin = bin < 0 ? 0 : (bin >= HB ? HB - 1 : bin);
+        atomicAdd(&hist[(le[m] == ln ? 0 : HB) + bin], 1u);
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < 2 * HB; i += 256) {
+    const unsigned c = hist[i];
+    if (c) atomicAdd((i < HB ? hist_tar : hist_non) + (i & (HB - 1)), (unsigned long long)c);
   }
 }
 
@@ -224,6 +310,24 @@ int sc_snorm_apply(float* d_S, int32_t Ne, int32_t Nt, const float* d_mean_e, co
   SK_CHECK(d_S && d_mean_e && d_std_e && d_mean_t && d_std_t && Ne > 0 && Nt > 0, SK_EARG, "sc_snorm_apply: bad arguments");
   hipLaunchKernelGGL(snorm_apply_kernel, dim3((unsigned)(((long)Ne * Nt + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_S, Ne, Nt,
                      d_mean_e, d_std_e, d_mean_t, d_std_t);
+  SK_HIP(hipGetLastError());
+  return SK_OK;
+}
+
+int sc_cosine_hist(const float* d_E, int32_t Ne, const float* d_T, int32_t Nt, int32_t D, const int32_t* d_labels_e, const int32_t* d_labels_t,
+                   int32_t self_offset, float lo, float hi, int32_t nbins, uint64_t* d_hist_tar, uint64_t* d_hist_non, void* stream) {
+  SK_CHECK(d_E && d_T && d_labels_e && d_labels_t && d_hist_tar && d_hist_non && Ne > 0 && Nt > 0 && D > 0 && D % 4 == 0, SK_EARG,
+           "sc_cosine_hist: bad arguments (D must be a multiple of 4)");
+  SK_CHECK(nbins == HB && hi > lo, SK_EARG, "sc_cosine_hist: nbins must be %d and hi > lo", HB);
+  hipStream_t st = (hipStream_t)stream;
+  SK_HIP(hipMemsetAsync(d_hist_tar, 0, (size_t)HB * 8, st));
+  SK_HIP(hipMemsetAsync(d_hist_non, 0, (size_t)HB * 8, st));
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  const long ntiles = (long)cdiv(Ne, 64) * cdiv(Nt, 64);
+  const int grid = (int)(ntiles < (long)cus ? ntiles : (long)cus);   // persistent: one workgroup per CU (64 KB of histograms + the operand tiles)
+  hipLaunchKernelGGL(cosine_hist_kernel, dim3(grid), dim3(256), 0, st, d_E, Ne, d_T, Nt, D, d_labels_e, d_labels_t, self_offset, lo,
+                     (float)HB / (hi - lo), (unsigned long long*)d_hist_tar, (unsigned long long*)d_hist_non);
   SK_HIP(hipGetLastError());
   return SK_OK;
 }

@@ -44,11 +44,18 @@ def _stream(device):
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
-def cosine_matrix(enroll_vectors, test_vectors, device=None):
-    """(Ne, D) x (Nt, D) already-normalised float vectors -> (Ne, Nt) float32 numpy matrix (GPU)."""
-    device = _device(device)
-    e = torch.as_tensor(numpy.ascontiguousarray(enroll_vectors, dtype=numpy.float32)).to(device)
-    t = torch.as_tensor(numpy.ascontiguousarray(test_vectors, dtype=numpy.float32)).to(device)
+def _to_device(x, dtype, device):
+    """numpy array or torch tensor (any device) -> contiguous tensor of `dtype` on `device`; a tensor already there is used as is."""
+    if torch.is_tensor(x):
+        return x.to(device=device, dtype=dtype).contiguous()
+    return torch.as_tensor(numpy.ascontiguousarray(x, dtype=numpy.float32 if dtype == torch.float32 else numpy.float64)).to(device)
+
+
+def cosine_matrix_device(enroll_vectors, test_vectors, device=None):
+    """(Ne, D) x (Nt, D) already-normalised vectors -> (Ne, Nt) float32 **device tensor**: x-vectors that are already on the GPU
+    (fresh from ``Xtractor.forward`` or an all-gather) are scored where they are, nothing crosses PCIe."""
+    device = _device(device if device is not None else (enroll_vectors.device if torch.is_tensor(enroll_vectors) and enroll_vectors.is_cuda else None))
+    e, t = _to_device(enroll_vectors, torch.float32, device), _to_device(test_vectors, torch.float32, device)
     D = e.shape[1]
     if D % 4:  # the GEMM wants K % 4 == 0: zero columns do not change a dot product
         pad = 4 - D % 4
@@ -59,118 +66,61 @@ def cosine_matrix(enroll_vectors, test_vectors, device=None):
     with torch.cuda.device(device):
         _lib.check(_lib.lib().sc_cosine(e.data_ptr(), e.shape[0], t.data_ptr(), t.shape[0], D, out.data_ptr(), _stream(device)),
                    AssertionError)
-    return out.cpu().numpy()
+    return out
 
 
-def plda_matrix(enroll_vectors, test_vectors, Phi, Psi, cst, scaling_factor=1., device=None):
-    """scaling * (0.5 e'Phi e + 0.5 t'Phi t + cst + e'Psi t) for all pairs, float64, on the GPU."""
-    device = _device(device)
-    dev = lambda a: torch.as_tensor(numpy.ascontiguousarray(a, dtype=numpy.float64)).to(device)
-    e, t, phi, psi = dev(enroll_vectors), dev(test_vectors), dev(Phi), dev(Psi)
+def cosine_matrix(enroll_vectors, test_vectors, device=None):
+    """(Ne, D) x (Nt, D) already-normalised float vectors -> (Ne, Nt) float32 numpy matrix (computed on the GPU)."""
+    return cosine_matrix_device(enroll_vectors, test_vectors, device).cpu().numpy()
+
+
+def plda_matrix_device(enroll_vectors, test_vectors, Phi, Psi, cst, scaling_factor=1., device=None):
+    """scaling * (0.5 e'Phi e + 0.5 t'Phi t + cst + e'Psi t) for all pairs, float64 **device tensor** (f64 MFMA GEMM)."""
+    device = _device(device if device is not None else (enroll_vectors.device if torch.is_tensor(enroll_vectors) and enroll_vectors.is_cuda else None))
+    e, t = _to_device(enroll_vectors, torch.float64, device), _to_device(test_vectors, torch.float64, device)
+    phi, psi = _to_device(Phi, torch.float64, device), _to_device(Psi, torch.float64, device)
     out = torch.empty((e.shape[0], t.shape[0]), dtype=torch.float64, device=device)
     with torch.cuda.device(device):
         _lib.check(_lib.lib().sc_plda_fast(e.data_ptr(), e.shape[0], t.data_ptr(), t.shape[0], e.shape[1], phi.data_ptr(),
                                            psi.data_ptr(), float(cst), float(scaling_factor), out.data_ptr(), _stream(device)),
                    AssertionError)
-    return out.cpu().numpy()
+    return out
 
 
-def _open_set(scoremat, p_known):
-    """Open-set identification term (iv_scoring.py:467-475): impostor mass = mean of the other models' likelihoods."""
-    N = scoremat.shape[0]
-    tmp = numpy.exp(scoremat)
-    others = tmp.sum(axis=0)[numpy.newaxis, :] - tmp
-    return scoremat - numpy.log(p_known * others / (N - 1) + (1 - p_known))
+def plda_matrix(enroll_vectors, test_vectors, Phi, Psi, cst, scaling_factor=1., device=None):
+    """Same, returned as a float64 numpy matrix."""
+    return plda_matrix_device(enroll_vectors, test_vectors, Phi, Psi, cst, scaling_factor, device).cpu().numpy()
 
 
-def cosine_scoring(enroll, test, ndx, wccn=None, check_missing=True, device=None):
-    """Cosine similarity of every (model, segment) pair of ``ndx``; returns a ``Scores`` (float32 matrix)."""
-    assert isinstance(enroll, StatServer), 'First parameter should be a StatServer'
-    assert isinstance(test, StatServer), 'Second parameter should be a StatServer'
-    assert isinstance(ndx, Ndx), 'Third parameter should be an Ndx'
-    enroll_copy = copy.deepcopy(enroll)
-    test_copy = copy.deepcopy(test)
-    clean_ndx = _check_missing_model(enroll_copy, test_copy, ndx) if check_missing else ndx
-    if wccn is not None:
-        enroll_copy.rotate_stat1(wccn)
-        test_copy.rotate_stat1(wccn)
-    enroll_copy.norm_stat1()
-    test_copy.norm_stat1()
-    score = Scores()
-    score.scoremat = cosine_matrix(enroll_copy.stat1, test_copy.stat1, device)
-    score.modelset = clean_ndx.modelset
-    score.segset = clean_ndx.segset
-    score.scoremask = clean_ndx.trialmask
-    return score
+HIST_BINS = 8192
 
 
-def PLDA_scoring(enroll, test, ndx, mu, F, G, Sigma, test_uncertainty=None, Vtrans=None, p_known=0.0, scaling_factor=1.,
-                 full_model=False):
-    """PLDA log-likelihood ratios; dispatches to the two-covariance form unless ``full_model``."""
-    assert isinstance(enroll, StatServer), 'First parameter should be a StatServer'
-    assert isinstance(test, StatServer), 'Second parameter should be a StatServer'
-    assert isinstance(ndx, Ndx), 'Third parameter should be an Ndx'
-    assert enroll.stat1.shape[1] == test.stat1.shape[1], 'I-vectors dimension mismatch'
-    assert enroll.stat1.shape[1] == F.shape[0], 'I-vectors and co-variance matrix dimension mismatch'
-    assert enroll.stat1.shape[1] == G.shape[0], 'I-vectors and co-variance matrix dimension mismatch'
-    if not full_model:
-        return fast_PLDA_scoring(enroll, test, ndx, mu, F, Sigma, test_uncertainty, Vtrans, p_known=p_known,
-                                 scaling_factor=scaling_factor, check_missing=True)
-    return full_PLDA_scoring(enroll, test, ndx, mu, F, G, Sigma, p_known=p_known, scaling_factor=scaling_factor)
+def cosine_histograms(enroll_vectors, test_vectors, enroll_labels, test_labels, self_offset=None, lo=-1.0, hi=1.0, device=None):
+    """Target / non-target score histograms of ALL (enrol, test) pairs without materialising the (Ne, Nt) score matrix
+    (SURVEY 8d: 100k x 100k cosine trials are 40 GB).  A trial is a target when the two integer labels are equal;
+    ``self_offset=k`` drops the self-trials ``j == i + k`` when the enrolment side is rows ``[k, k + Ne)`` of the test side (``0`` for
+    a set scored against itself, a shard's first row for one rank's block of it); ``None`` keeps every pair.  Returns two uint64 arrays of
+    ``HIST_BINS`` equal bins over ``[lo, hi)``; ``bosaris.detplot.eer_from_histograms`` turns them into the ROCCH EER."""
+    device = _device(device if device is not None else (enroll_vectors.device if torch.is_tensor(enroll_vectors) and enroll_vectors.is_cuda else None))
+    e, t = _to_device(enroll_vectors, torch.float32, device), _to_device(test_vectors, torch.float32, device)
+    if e.shape[1] % 4 or e.shape[1] != t.shape[1]:
+        raise AssertionError("x-vector dimensions must match and be a multiple of 4")
+    le = torch.as_tensor(enroll_labels).to(device=device, dtype=torch.int32).contiguous()
+    lt = torch.as_tensor(test_labels).to(device=device, dtype=torch.int32).contiguous()
+    assert le.shape == (e.shape[0],) and lt.shape == (t.shape[0],), "one label per vector"
+    ht = torch.empty(HIST_BINS, dtype=torch.int64, device=device)
+    hn = torch.empty(HIST_BINS, dtype=torch.int64, device=device)
+    with torch.cuda.device(device):
+        _lib.check(_lib.lib().sc_cosine_hist(e.data_ptr(), e.shape[0], t.data_ptr(), t.shape[0], e.shape[1], le.data_ptr(), lt.data_ptr(),
+                                             -1 if self_offset is None else int(self_offset), float(lo), float(hi), HIST_BINS, ht.data_ptr(), hn.data_ptr(),
+                                             _stream(device)), AssertionError)
+    return ht.cpu().numpy().astype(numpy.uint64), hn.cpu().numpy().astype(numpy.uint64)
 
 
-def full_PLDA_scoring(enroll, test, ndx, mu, F, G, Sigma, p_known=0.0, scaling_factor=1., check_missing=True, device=None):
-    """PLDA with a channel sub-space G."""
-    enroll_copy = copy.deepcopy(enroll)
-    test_copy = copy.deepcopy(test)
-    clean_ndx = _check_missing_model(enroll_copy, test_copy, ndx) if check_missing else ndx
-    enroll_copy.center_stat1(mu)
-    test_copy.center_stat1(mu)
-    invSigma = scipy.linalg.inv(Sigma)
-    I_iv = numpy.eye(mu.shape[0], dtype='float')
-    I_ch = numpy.eye(G.shape[1], dtype='float')
-    I_spk = numpy.eye(F.shape[1], dtype='float')
-    A = numpy.linalg.inv(G.T.dot(invSigma * scaling_factor).dot(G) + I_ch)
-    B = F.T.dot(invSigma * scaling_factor).dot(I_iv - G.dot(A).dot(G.T).dot(invSigma * scaling_factor))
-    K = B.dot(F)
-    K1 = scipy.linalg.inv(K + I_spk)
-    K2 = scipy.linalg.inv(2 * K + I_spk)
-    constant = numpy.linalg.slogdet(K2)[1] / 2.0 - numpy.linalg.slogdet(K1)[1]
-    enroll_tmp = enroll_copy.stat1.dot(B.T)   # (Ne, rank): speaker-subspace projections
-    test_tmp = test_copy.stat1.dot(B.T)
-    score = Scores()
-    score.scoremat = plda_matrix(enroll_tmp, test_tmp, K2 - K1, 0.5 * (K2 + K2.T), constant, scaling_factor, device)
-    score.modelset = clean_ndx.modelset
-    score.segset = clean_ndx.segset
-    score.scoremask = clean_ndx.trialmask
-    if p_known != 0:
-        score.scoremat = _open_set(score.scoremat, p_known)
-    return score
-
-
-def fast_PLDA_scoring(enroll, test, ndx, mu, F, Sigma, test_uncertainty=None, Vtrans=None, p_known=0.0, scaling_factor=1.,
-                      check_missing=True, device=None):
-    """Two-covariance PLDA scoring of all trials of ``ndx`` (float64)."""
-    enroll_ctr = copy.deepcopy(enroll)
-    test_ctr = copy.deepcopy(test)
-    if not numpy.unique(enroll_ctr.modelset).shape == enroll_ctr.modelset.shape:
-        logging.warning("Enrollment models are not unique, average i-vectors")
-        enroll_ctr = enroll_ctr.mean_stat_per_model()
-    clean_ndx = _check_missing_model(enroll_ctr, test_ctr, ndx) if check_missing else ndx
-    enroll_ctr.center_stat1(mu)
-    test_ctr.center_stat1(mu)
-    invSigma = scipy.linalg.inv(Sigma)
-    I_spk = numpy.eye(F.shape[1], dtype='float')
-    K = F.T.dot(invSigma * scaling_factor).dot(F)
-    K1 = scipy.linalg.inv(K + I_spk)
-    K2 = scipy.linalg.inv(2 * K + I_spk)
-    plda_cst = numpy.linalg.slogdet(K2)[1] / 2.0 - numpy.linalg.slogdet(K1)[1]
-    Sigma_ac = numpy.dot(F, F.T)
-    Sigma_tot = Sigma_ac + Sigma
-    Sigma_tot_inv = scipy.linalg.inv(Sigma_tot)
-    Tmp = numpy.linalg.inv(Sigma_tot - Sigma_ac.dot(Sigma_tot_inv).dot(Sigma_ac))
-    Phi = Sigma_tot_inv - Tmp
-    Psi = Sigma_tot_inv.dot(Sigma_ac).dot(Tmp)
+def plda_parameters(mu, F, Sigma, scaling_factor=1.):
+    """The 256 x 256 float64 algebra of ``fast_PLDA_scoring`` (``iv_scoring.py:428-446``): ``(Phi, Psi, plda_cst)`` such that
+    ``score(e, t) = scaling * (0.5 e'Phi e + 0.5 t'Phi t + plda_cst + e'Psi t)`` for centred vectors."""
+    Phi, Psi, plda_cst = plda_parameters(mu, F, Sigma, scaling_factor)
     score = Scores()
     score.modelset = clean_ndx.modelset
     score.segset = clean_ndx.segset

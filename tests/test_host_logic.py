@@ -171,3 +171,24 @@ def test_product_frontend_constants_equal_oracle():
     b = pp.MfccFrontEnd().buffers()
     assert torch.equal(b["MFCC.MelSpectrogram.mel_scale.fb"], ofe.mel_filterbank(1025, 133.333, 6855.4976, 100, 16000))
     assert torch.equal(b["MFCC.dct_mat"], ofe.dct_matrix(80, 100))
+
+
+def test_histogram_eer_is_the_rocch_eer_of_the_binned_scores():
+    from sidekit_amd.bosaris import eer_from_histograms, rocch_from_histograms
+    rs = numpy.random.RandomState(0)
+    tar = numpy.clip(rs.randn(3000) * 0.15 + 0.45, -1, 0.9999)
+    non = numpy.clip(rs.randn(40000) * 0.12, -1, 0.9999)
+    nb = 8192
+    bt, bn = numpy.floor((tar + 1) * nb / 2).astype(int), numpy.floor((non + 1) * nb / 2).astype(int)
+    ht, hn = numpy.bincount(bt, minlength=nb), numpy.bincount(bn, minlength=nb)
+    eer_h = eer_from_histograms(ht, hn)
+    assert abs(eer_h - rocch2eer(*rocch(bt.astype(float), bn.astype(float)))) < 1e-15       # ties with multiplicities == weighted bins
+    assert abs(eer_h - rocch2eer(*rocch(tar, non))) < 5e-4                                    # +-0.05 % absolute of the exact EER
+    pm, pf = rocch_from_histograms(ht, hn)
+    assert pm[0] == 0 and pf[0] == 1 and pm[-1] == 1 and pf[-1] == 0 and numpy.all(numpy.diff(pm) >= 0) and numpy.all(numpy.diff(pf) <= 0)
+    # perfectly separated and fully mixed histograms
+    a, b = numpy.zeros(16), numpy.zeros(16)
+    a[12], b[3] = 5, 7
+    assert eer_from_histograms(a, b) == 0
+    a[:], b[:] = 1, 1
+    assert abs(eer_from_histograms(a, b) - 0.5) < 1e-12
