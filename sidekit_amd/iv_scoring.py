@@ -120,6 +120,105 @@ def cosine_histograms(enroll_vectors, test_vectors, enroll_labels, test_labels, 
 def plda_parameters(mu, F, Sigma, scaling_factor=1.):
     """The 256 x 256 float64 algebra of ``fast_PLDA_scoring`` (``iv_scoring.py:428-446``): ``(Phi, Psi, plda_cst)`` such that
     ``score(e, t) = scaling * (0.5 e'Phi e + 0.5 t'Phi t + plda_cst + e'Psi t)`` for centred vectors."""
+    invSigma = scipy.linalg.inv(Sigma)
+    I_spk = numpy.eye(F.shape[1], dtype='float')
+    K = F.T.dot(invSigma * scaling_factor).dot(F)
+    K1 = scipy.linalg.inv(K + I_spk)
+    K2 = scipy.linalg.inv(2 * K + I_spk)
+    plda_cst = numpy.linalg.slogdet(K2)[1] / 2.0 - numpy.linalg.slogdet(K1)[1]
+    Sigma_ac = numpy.dot(F, F.T)
+    Sigma_tot = Sigma_ac + Sigma
+    Sigma_tot_inv = scipy.linalg.inv(Sigma_tot)
+    Tmp = numpy.linalg.inv(Sigma_tot - Sigma_ac.dot(Sigma_tot_inv).dot(Sigma_ac))
+    Phi = Sigma_tot_inv - Tmp
+    Psi = Sigma_tot_inv.dot(Sigma_ac).dot(Tmp)
+    return Phi, Psi, plda_cst
+
+
+def _open_set(scoremat, p_known):
+    """Open-set identification term (iv_scoring.py:467-475): impostor mass = mean of the other models' likelihoods."""
+    N = scoremat.shape[0]
+    tmp = numpy.exp(scoremat)
+    others = tmp.sum(axis=0)[numpy.newaxis, :] - tmp
+    return scoremat - numpy.log(p_known * others / (N - 1) + (1 - p_known))
+
+
+def cosine_scoring(enroll, test, ndx, wccn=None, check_missing=True, device=None):
+    """Cosine similarity of every (model, segment) pair of ``ndx``; returns a ``Scores`` (float32 matrix)."""
+    assert isinstance(enroll, StatServer), 'First parameter should be a StatServer'
+    assert isinstance(test, StatServer), 'Second parameter should be a StatServer'
+    assert isinstance(ndx, Ndx), 'Third parameter should be an Ndx'
+    enroll_copy = copy.deepcopy(enroll)
+    test_copy = copy.deepcopy(test)
+    clean_ndx = _check_missing_model(enroll_copy, test_copy, ndx) if check_missing else ndx
+    if wccn is not None:
+        enroll_copy.rotate_stat1(wccn)
+        test_copy.rotate_stat1(wccn)
+    enroll_copy.norm_stat1()
+    test_copy.norm_stat1()
+    score = Scores()
+    score.scoremat = cosine_matrix(enroll_copy.stat1, test_copy.stat1, device)
+    score.modelset = clean_ndx.modelset
+    score.segset = clean_ndx.segset
+    score.scoremask = clean_ndx.trialmask
+    return score
+
+
+def PLDA_scoring(enroll, test, ndx, mu, F, G, Sigma, test_uncertainty=None, Vtrans=None, p_known=0.0, scaling_factor=1.,
+                 full_model=False):
+    """PLDA log-likelihood ratios; dispatches to the two-covariance form unless ``full_model``."""
+    assert isinstance(enroll, StatServer), 'First parameter should be a StatServer'
+    assert isinstance(test, StatServer), 'Second parameter should be a StatServer'
+    assert isinstance(ndx, Ndx), 'Third parameter should be an Ndx'
+    assert enroll.stat1.shape[1] == test.stat1.shape[1], 'I-vectors dimension mismatch'
+    assert enroll.stat1.shape[1] == F.shape[0], 'I-vectors and co-variance matrix dimension mismatch'
+    assert enroll.stat1.shape[1] == G.shape[0], 'I-vectors and co-variance matrix dimension mismatch'
+    if not full_model:
+        return fast_PLDA_scoring(enroll, test, ndx, mu, F, Sigma, test_uncertainty, Vtrans, p_known=p_known,
+                                 scaling_factor=scaling_factor, check_missing=True)
+    return full_PLDA_scoring(enroll, test, ndx, mu, F, G, Sigma, p_known=p_known, scaling_factor=scaling_factor)
+
+
+def full_PLDA_scoring(enroll, test, ndx, mu, F, G, Sigma, p_known=0.0, scaling_factor=1., check_missing=True, device=None):
+    """PLDA with a channel sub-space G."""
+    enroll_copy = copy.deepcopy(enroll)
+    test_copy = copy.deepcopy(test)
+    clean_ndx = _check_missing_model(enroll_copy, test_copy, ndx) if check_missing else ndx
+    enroll_copy.center_stat1(mu)
+    test_copy.center_stat1(mu)
+    invSigma = scipy.linalg.inv(Sigma)
+    I_iv = numpy.eye(mu.shape[0], dtype='float')
+    I_ch = numpy.eye(G.shape[1], dtype='float')
+    I_spk = numpy.eye(F.shape[1], dtype='float')
+    A = numpy.linalg.inv(G.T.dot(invSigma * scaling_factor).dot(G) + I_ch)
+    B = F.T.dot(invSigma * scaling_factor).dot(I_iv - G.dot(A).dot(G.T).dot(invSigma * scaling_factor))
+    K = B.dot(F)
+    K1 = scipy.linalg.inv(K + I_spk)
+    K2 = scipy.linalg.inv(2 * K + I_spk)
+    constant = numpy.linalg.slogdet(K2)[1] / 2.0 - numpy.linalg.slogdet(K1)[1]
+    enroll_tmp = enroll_copy.stat1.dot(B.T)   # (Ne, rank): speaker-subspace projections
+    test_tmp = test_copy.stat1.dot(B.T)
+    score = Scores()
+    score.scoremat = plda_matrix(enroll_tmp, test_tmp, K2 - K1, 0.5 * (K2 + K2.T), constant, scaling_factor, device)
+    score.modelset = clean_ndx.modelset
+    score.segset = clean_ndx.segset
+    score.scoremask = clean_ndx.trialmask
+    if p_known != 0:
+        score.scoremat = _open_set(score.scoremat, p_known)
+    return score
+
+
+def fast_PLDA_scoring(enroll, test, ndx, mu, F, Sigma, test_uncertainty=None, Vtrans=None, p_known=0.0, scaling_factor=1.,
+                      check_missing=True, device=None):
+    """Two-covariance PLDA scoring of all trials of ``ndx`` (float64)."""
+    enroll_ctr = copy.deepcopy(enroll)
+    test_ctr = copy.deepcopy(test)
+    if not numpy.unique(enroll_ctr.modelset).shape == enroll_ctr.modelset.shape:
+        logging.warning("Enrollment models are not unique, average i-vectors")
+        enroll_ctr = enroll_ctr.mean_stat_per_model()
+    clean_ndx = _check_missing_model(enroll_ctr, test_ctr, ndx) if check_missing else ndx
+    enroll_ctr.center_stat1(mu)
+    test_ctr.center_stat1(mu)
     Phi, Psi, plda_cst = plda_parameters(mu, F, Sigma, scaling_factor)
     score = Scores()
     score.modelset = clean_ndx.modelset

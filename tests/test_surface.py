@@ -1,0 +1,79 @@
+"""The reference's Python surface for the hot path is all there -- checked without a GPU: names, signatures'
+leading parameters, and the `install_as_sidekit()` aliases.  (Compute through these names is covered by the -m gpu tests.)"""
+import inspect
+import sys
+
+import numpy
+
+SURFACE = {
+    "iv_scoring": {"cosine_scoring": ["enroll", "test", "ndx", "wccn", "check_missing", "device"],
+                   "PLDA_scoring": ["enroll", "test", "ndx", "mu", "F", "G", "Sigma", "test_uncertainty", "Vtrans", "p_known", "scaling_factor", "full_model"],
+                   "fast_PLDA_scoring": ["enroll", "test", "ndx", "mu", "F", "Sigma", "test_uncertainty", "Vtrans", "p_known", "scaling_factor", "check_missing"],
+                   "full_PLDA_scoring": ["enroll", "test", "ndx", "mu", "F", "G", "Sigma", "p_known", "scaling_factor"],
+                   "cosine_matrix": None, "cosine_matrix_device": None, "plda_matrix": None, "plda_matrix_device": None,
+                   "cosine_histograms": None, "plda_parameters": None},
+    "score_normalization": {"asnorm": ["enrol_xv", "cohort_xv", "ndx"]},
+    "statserver": {"StatServer": None},
+    "sidekit_io": {"read_plda_hdf5": ["input_filename"], "write_plda_hdf5": ["data", "output_filename"], "write_norm_hdf5": None,
+                   "read_norm_hdf5": None, "write_matrix_hdf5": None, "read_matrix_hdf5": None, "read_dict_hdf5": None},
+    "bosaris": {"IdMap": None, "Ndx": None, "Key": None, "Scores": None, "rocch": None, "rocch2eer": None, "pavx": None,
+                "fast_minDCF": None, "effective_prior": None, "logit_effective_prior": None},
+    "bosaris.detplot": {"rocch": ["tar_scores", "nontar_scores"], "rocch2eer": ["pmiss", "pfa"], "pavx": ["y"], "sigmoid": None,
+                        "fast_minDCF": ["tar", "non", "plo", "normalize"]},
+    "nnet.xvector": {"Xtractor": None, "extract_embeddings": ["idmap_name", "model_filename", "data_root_name", "device", "batch_size",
+                                                               "file_extension", "transform_pipeline", "sliding_window", "win_duration",
+                                                               "win_shift", "num_thread", "sample_rate", "mixed_precision", "norm_embeddings"],
+                     "extract_embeddings_per_speaker": None, "test_metrics": ["model", "device", "model_opts", "data_opts", "train_opts", "as_norm"]},
+    "nnet": {"Xtractor": None, "extract_embeddings": None, "MelSpecFrontEnd": None, "MfccFrontEnd": None},
+}
+METHODS = {
+    ("statserver", "StatServer"): ["validate", "align_models", "align_segments", "norm_stat1", "rotate_stat1", "center_stat1", "whiten_stat1",
+                                   "get_mean_stat1", "mean_stat_per_model", "read", "write"],
+    ("bosaris", "Ndx"): ["validate", "filter", "save_txt", "read_txt", "merge", "read", "write"],
+    ("bosaris", "Key"): ["validate", "to_ndx", "filter", "write_txt", "read_txt", "read", "write"],
+    ("bosaris", "Scores"): ["validate", "get_tar_non", "align_with_ndx", "set_missing_to_value", "filter", "sort", "get_score", "write_txt",
+                            "read_txt", "read", "write"],
+    ("bosaris", "IdMap"): ["set", "validate", "map_left_to_right", "map_right_to_left", "filter_on_left", "filter_on_right", "merge",
+                           "write_txt", "read_txt", "read", "write"],
+    ("nnet.xvector", "Xtractor"): ["forward", "load_state_dict", "state_dict", "to", "eval", "context_size", "parameters"],
+}
+
+
+def test_reference_surface_is_complete():
+    import importlib
+    for mod, names in SURFACE.items():
+        m = importlib.import_module("sidekit_amd." + mod)
+        for name, params in names.items():
+            assert hasattr(m, name), f"sidekit_amd.{mod}.{name} is missing"
+            if params:
+                got = list(inspect.signature(getattr(m, name)).parameters)
+                assert got[:len(params)] == params, (mod, name, got)
+    for (mod, cls), methods in METHODS.items():
+        c = getattr(importlib.import_module("sidekit_amd." + mod), cls)
+        for meth in methods:
+            assert callable(getattr(c, meth, None)), f"{cls}.{meth} is missing"
+    xt = importlib.import_module("sidekit_amd.nnet.xvector").Xtractor
+    assert list(inspect.signature(xt.__init__).parameters)[1:8] == ["speaker_number", "model_archi", "loss", "norm_embedding", "aam_margin",
+                                                                     "aam_s", "embedding_size"]          # xvector.py:424-431
+
+
+def test_install_as_sidekit_aliases_every_module():
+    import sidekit_amd
+    saved = {k: v for k, v in sys.modules.items() if k == "sidekit" or k.startswith("sidekit.")}
+    try:
+        pkg = sidekit_amd.install_as_sidekit()
+        import sidekit
+        assert sidekit is pkg is sidekit_amd
+        for sub in sidekit_amd.SUBMODULES:
+            assert sys.modules["sidekit." + sub] is sys.modules["sidekit_amd." + sub]
+        from sidekit.nnet.xvector import Xtractor                       # noqa: F401  (the reference's own import lines)
+        from sidekit.iv_scoring import cosine_scoring                   # noqa: F401
+        from sidekit.bosaris.detplot import rocch                       # noqa: F401
+        from sidekit.score_normalization import asnorm                  # noqa: F401
+        from sidekit.sidekit_io import read_plda_hdf5                   # noqa: F401
+        assert sidekit.StatServer is sys.modules["sidekit_amd.statserver"].StatServer and sidekit.fast_PLDA_scoring is sys.modules["sidekit_amd.iv_scoring"].fast_PLDA_scoring
+        assert sidekit.STAT_TYPE is numpy.float64 and sidekit.PARAM_TYPE is numpy.float32 and sidekit.PARALLEL_MODULE == "multiprocessing"
+    finally:
+        for k in [k for k in sys.modules if k == "sidekit" or k.startswith("sidekit.")]:
+            del sys.modules[k]
+        sys.modules.update(saved)
