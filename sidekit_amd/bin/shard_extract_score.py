@@ -76,7 +76,7 @@ def main(argv=None):
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--trials", type=int, default=1000, help="enrolment models = test segments = this many (full trial mask)")
     ap.add_argument("--speakers", type=int, default=250)
-    ap.add_argument("--noise", type=float, default=0.12, help="white-noise level of the synthetic utterances (sets the EER)")
+    ap.add_argument("--noise", type=float, default=0.004, help="white-noise level of the synthetic utterances (sets the EER: 0.004 -> cosine ~15 %, PLDA ~10 %; 0.03 -> 46 %)")
     ap.add_argument("--plda-rank", type=int, default=128)
     ap.add_argument("--all-pairs", action="store_true", help="also score every pair of the corpus into histograms (no N x N matrix)")
     args = ap.parse_args(argv)

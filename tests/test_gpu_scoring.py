@@ -211,5 +211,6 @@ def test_sharded_driver_single_rank(gpu, capsys):
     d = json.loads(line)
     assert d["ranks"] == 1 and d["trials"] == 250000 and d["all_pairs"] == 1600 * 1599
     for k in ("cosine_eer", "plda_eer", "all_pairs_eer"):
-        assert 0.0 <= d[k] < 0.45, (k, d[k])                       # the random-weight extractor separates the synthetic speakers
-    assert abs(d["cosine_eer"] - d["all_pairs_eer"]) < 0.1         # same score distribution, different trial subsets
+        assert 0.0 <= d[k] < 0.3, (k, d[k])                        # the random-weight extractor separates the synthetic speakers
+    assert d["plda_eer"] < d["cosine_eer"] + 0.02                  # PLDA trained on the held-out part of the same x-vectors is no worse
+    assert abs(d["cosine_eer"] - d["all_pairs_eer"]) < 0.05        # same score distribution, different trial subsets
