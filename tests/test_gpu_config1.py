@@ -203,7 +203,8 @@ def test_install_as_sidekit_runs_reference_style_callers(gpu, ex, tmp_path):
 
 # per-stage relative-error budgets of the bf16 trunk against the fp32 oracle: bf16 rounding (2^-9 per stored value) grows with
 # depth; a stage that breaks its budget localises a defect that the final cosine would wash out
-BF16_BUDGET = {"stem": 4e-3, "layer1": 1.2e-2, "layer2": 2e-2, "layer3": 3e-2, "layer4": 4e-2, "pooled": 4e-2}
+# measured (scripts/bf16_stage_errors.py, T = 52 .. 801): stem 1.66e-3, layer1 4.4e-3, layer2 5.9e-3, layer3 8.5e-3 .. 9.3e-3, layer4 1.1e-2 .. 1.5e-2
+BF16_BUDGET = {"stem": 2.5e-3, "layer1": 7e-3, "layer2": 9e-3, "layer3": 1.4e-2, "layer4": 2.2e-2}
 
 
 def _bf16(buf):
@@ -220,7 +221,7 @@ def test_bf16_stage_taps_against_the_fp32_oracle(gpu, case):
     frames = [401, 401] if case == "t401" else [401, 137, 260, 52]
     T = max(frames)
     feats = torch.randn(len(frames), 80, T, generator=g)
-    names = ["stem", "layer1", "layer2", "layer3", "layer4", "pooled"]
+    names = ["stem", "layer1", "layer2", "layer3", "layer4"]
     model.set_debug(True)
     _, emb = model.forward_features(feats.cuda(), frames=frames if case == "ragged" else None)
     raw = model.debug_taps(names)
@@ -229,7 +230,7 @@ def test_bf16_stage_taps_against_the_fp32_oracle(gpu, case):
         taps = {}
         with torch.no_grad():
             _, o_emb = oxv.halfresnet34_from_feats(feats[b:b + 1, :, :t], sd, taps=taps)
-        for li, name in enumerate(names[:5]):
+        for li, name in enumerate(names):
             ref = taps[name][0]                                            # (C, H, W) of this utterance
             C, H, W = ref.shape
             Hmax = T
@@ -240,4 +241,4 @@ def test_bf16_stage_taps_against_the_fp32_oracle(gpu, case):
             assert err < BF16_BUDGET[name], (case, b, name, err)
             assert err > 1e-4 or name == "stem", (case, b, name, err)      # really the bf16 path
         cos = float(torch.nn.functional.cosine_similarity(emb[b:b + 1].cpu(), o_emb))
-        assert cos > 0.999, (case, b, cos)
+        assert cos > 0.9995, (case, b, cos)                              # measured 1 - cos = 5e-5 .. 7e-5
