@@ -134,3 +134,52 @@ def dense_reads(W, TH, CB, MW):
                     cyc = read_cycles(addrs)
                     tot += cyc; n += 1; worst = max(worst, cyc)
     return tot / n, worst
+
+
+# ---- 16x16x32 MFMA operand reads: lane l holds position l & 15 of a 16-position tile and 16-B chunk (4 * s + (l >> 4)) ----------
+def m16_grid(W, TH, CB, MW, WM, GR, GC, rmask, rshift, csh, cmask, lead):
+    SPP = CB // 16
+    RS = (W + 1) * CB
+    KS32 = CB // 64
+    img0 = CB if lead else 0
+    tot = n = worst = 0
+    for wm in range(WM):
+        for t in range(2 * MW):
+            br, bc = 2 * wm + t // MW, t % MW
+            for dh in range(3):
+                for dw in range(3):
+                    for s in range(KS32):
+                        addrs = []
+                        for lane in range(64):
+                            p, q = lane & 15, lane >> 4
+                            row = br * GR + p // GC + dh
+                            col = bc * GC + p % GC + dw - 1
+                            key = ((row & rmask) << rshift) ^ ((col >> csh) & cmask)
+                            if lead:
+                                pos = row * (W + 1) + col
+                            else:
+                                pos = row * (W + 1) + (W if col < 0 else col)
+                            c = 4 * s + q
+                            addrs.append(img0 + pos * CB + (((c ^ key) & (SPP - 1)) << 4) + ((c & ~(SPP - 1)) << 4))
+                        cyc = read_cycles(addrs)
+                        tot += cyc; n += 1; worst = max(worst, cyc)
+    return tot / n, worst
+
+
+def m16_dense(W, TH, MT16, K, perm):
+    """DENSE with 16-position tiles: lane p of tile t owns padded-image position 16 t + perm[p]; swizzle key K[(index) & 15]."""
+    CB = 256
+    tot = n = worst = 0
+    for t in range(MT16):
+        for dh in range(3):
+            for dw in range(3):
+                for s in range(4):
+                    addrs = []
+                    for lane in range(64):
+                        p, q = lane & 15, lane >> 4
+                        lm = 16 * t + perm[p] + dh * (W + 1) + dw - 1
+                        c = 4 * s + q
+                        addrs.append((lm + 1) * CB + ((c ^ K[lm & 15]) << 4))
+                    cyc = read_cycles(addrs)
+                    tot += cyc; n += 1; worst = max(worst, cyc)
+    return tot / n, worst

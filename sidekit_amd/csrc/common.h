@@ -106,6 +106,19 @@ __device__ inline float half_sum_upper_row(float v) {
   return v;
 }
 
+// Sum over each 16-lane row of the wave (the first four DPP steps of half_sum_upper_row): valid in every lane of the row.
+__device__ inline float row_sum16(float v) {
+  auto dpp = [](float x, auto ctrl) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xf, 0xf, false));
+  };
+  using std::integral_constant;
+  v += dpp(v, integral_constant<int, 0xB1>{});    // quad_perm [1,0,3,2]
+  v += dpp(v, integral_constant<int, 0x4E>{});    // quad_perm [2,3,0,1]
+  v += dpp(v, integral_constant<int, 0x141>{});   // row_half_mirror
+  v += dpp(v, integral_constant<int, 0x140>{});   // row_mirror
+  return v;
+}
+
 __device__ inline float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);

@@ -38,7 +38,7 @@ template <> __device__ inline void mma_step<float>(f32x16& acc, const uint4& w, 
 }
 
 enum { LANES_LINEAR = 0, LANES_GRID = 1, LANES_DENSE = 2 };
-template <typename T_, int CIN_, int COUT_, int S_, int WIN_, int TH_, int WM_, int WN_, int MW_, int NW_, int CK_, int TAPS_, int OCC_ = 0, int PD_ = 0, bool SWZ_ = false, int BLK_ = LANES_LINEAR>
+template <typename T_, int CIN_, int COUT_, int S_, int WIN_, int TH_, int WM_, int WN_, int MW_, int NW_, int CK_, int TAPS_, int OCC_ = 0, int PD_ = 0, bool SWZ_ = false, int BLK_ = LANES_LINEAR, bool M16_ = false>
 struct ConvCfg {
   using T = T_;
   static constexpr int EB = elem<T_>::bytes;
@@ -82,6 +82,13 @@ struct ConvCfg {
   static_assert(BLK != LANES_DENSE || (WM_ == 1 && CK_ * elem<T_>::bytes == 256 && TH_ * (WIN_ + 1) <= MW_ * 32), "DENSE: 256-B positions, one wave row");
   // a leading zero position in front of the image makes column -1 of a row the physically preceding position (no address
   // remap); layer 3 has no room for it (53760 B = 42 LDS granules exactly) and remaps column -1 of block column 0 instead
+  // MFMA shape.  M16: v_mfma_f32_16x16x32_bf16 instead of 32x32x16 -- the same FLOPs per matrix-pipe cycle and the same operand
+  // bytes per FLOP, but the chip holds a much higher clock on it (bare MFMA loops on random operands: 2.1 vs 1.65 GHz,
+  // scripts/probe_mfma_power.hip; layer 3 timed with this shape: 102 vs 151 us).  A lane then owns ONE position (l & 15) of a
+  // 16-position tile = one read-group block (GRID) or 16 consecutive padded-image positions (DENSE), and the 16-B chunk
+  // 4 * s + (l >> 4) of a 32-channel k-step s; its accumulator holds output channels 4 * (l >> 4) .. + 3 of a 16-channel tile.
+  static constexpr bool M16 = M16_;
+  static_assert(!M16 || (BLK != LANES_LINEAR && elem<T_>::bytes == 2 && (CK_ * 2) % 64 == 0), "M16: bf16, block lane orders, 64-B k-steps");
   static constexpr bool LEAD = BLK == LANES_DENSE || (BLK == LANES_GRID && CK_ * elem<T_>::bytes < 256);
   static constexpr int IMG0 = LEAD ? CK_ * elem<T_>::bytes : 0;
   static constexpr int PSTRIDE = SWZ ? CB : CB + 16;
@@ -110,11 +117,23 @@ struct ConvCfg {
   // CU whenever two halo tiles fit the LDS and the accumulators are small enough
   static constexpr int OCC = OCC_ ? OCC_ : ((MW * NW <= 5 && 160 * 1024 / LDS * WM * WN >= 8) ? 2 : 1);
   static constexpr int NK = TAPS * KS;           // k-steps per channel chunk
+  static constexpr int KS32 = CB / 64, NK32 = TAPS * KS32, KTOT32 = NCH * NK32;   // M16: 32-channel k-steps
+  static constexpr int MT16 = 2 * MW, NT16 = 2 * NW;                              // M16: position / output-channel tiles of 16 per wave
   static constexpr int PD = PD_ ? PD_ : ((NK * NW <= 24) ? NK : (NW == 1 ? 8 : 4));   // weight prefetch depth in k-steps
-  static constexpr bool RESIDENT = TAPS == 9 && NCH == 1 && PD == NK && NT == COUT;   // a wave keeps all its weight fragments in registers
+  static constexpr int PD16 = NK32 * NT16 <= 18 ? NK32 : 2;                             // M16: depth in 32-channel steps (two 1-KB fragments each per NW)
+  static constexpr bool RESIDENT = TAPS == 9 && NCH == 1 && (M16 ? PD16 == NK32 : PD == NK) && NT == COUT;   // a wave keeps all its weight fragments in registers
   static constexpr bool LEAN = RESIDENT || OCC >= 3;   // register-lean epilogue (constants per channel group, shortcut prefetch in two halves)
   static_assert(MT <= WM * MW * 32, "positions must be covered by the waves' 32-row MFMA tiles (trailing tiles may be partial or idle)");
   static constexpr bool PARTIAL_M = MT < WM * MW * 32;   // lanes past the tile compute on a duplicate of the last position and store nothing
+  // M16: tile-linear output position of lane position p (0..15) of 16-position tile t of wave row wm; >= MT: none
+  __device__ static inline int lane_pos16(int wm, int t, int p) {
+    if constexpr (BLK == LANES_GRID) {
+      return ((2 * wm + t / MW) * GR + p / GC) * WOUT + (t % MW) * GC + p % GC;
+    } else {
+      const int L = t * 16 + p, row = L / (WIN + 1), col = L % (WIN + 1);
+      return (col < WIN && row < TH) ? row * WOUT + col : MT;
+    }
+  }
   // tile-linear output position (row * WOUT + col) of lane r (0..31) of M-tile i of wave row wm; >= MT: the lane owns none
   __device__ static inline int lane_pos(int wm, int i, int r) {
     if constexpr (BLK == LANES_GRID) {
@@ -176,7 +195,16 @@ void conv3x3_kernel(ConvArgs a) {
   constexpr int NTR = (C::BLK == LANES_GRID && C::GR >= 4) ? 3 : 1;   // distinct row variants of the key
   int tapreg[C::BLK == LANES_GRID ? NTR : 1][3];
   int fixreg = 0;   // GRID without a leading zero position: column -1 of block column 0 is the row's own trailing zero position
-  if constexpr (C::BLK == LANES_GRID) {
+  if constexpr (C::BLK == LANES_GRID && C::M16) {
+    const int p = lane & 15, q = lane >> 4;
+    const int row0 = p / C::GC, col0 = p % C::GC;    // inside the 16-position block; the block's own offset is an immediate (+ the wave row)
+    const int lanebase = (2 * wm * C::GR + row0) * C::RS + col0 * C::CB;
+#pragma unroll
+    for (int t = 0; t < NTR; ++t)
+#pragma unroll
+      for (int dw = 0; dw < 3; ++dw) tapreg[t][dw] = lanebase + ((C::swz_key(row0 + t, col0 + dw - 1) ^ q) << 4);
+    if constexpr (!C::LEAD) fixreg = col0 == 0 ? C::RS - C::CB : -C::CB;
+  } else if constexpr (C::BLK == LANES_GRID) {
     const int g = ((r >= 4 && r < 12) || (r >= 16 && r < 20) || r >= 28) ? 1 : 0;
     const int j = r - (r < 4 ? 0 : (r < 12 ? 4 : (r < 20 ? 8 : (r < 28 ? 12 : 16))));
     const int row0 = (2 * wm + g) * C::GR + j / C::GC, col0 = j % C::GC;
@@ -224,9 +252,23 @@ void conv3x3_kernel(ConvArgs a) {
   auto kord = [](int kk) {
     return (C::SWZ && C::TAPS == 9 && !C::BLK) ? ((kk % 3) * 3 + kk / (3 * C::KS)) * C::KS + (kk / 3) % C::KS : kk;
   };
-  uint4 wq[PD][C::NW];
+  uint4 wq[C::M16 ? 1 : PD][C::NW];
+  // M16: fragments of 16 output channels x 32 input channels; a wave's 32-channel tile j is the pair of 16-channel tiles 2j, 2j + 1
+  constexpr int PD16 = C::PD16, NK32 = C::NK32;
+  uint4 wq16[C::M16 ? PD16 : 1][C::M16 ? C::NT16 : 1];
+  auto wload16 = [&](int jn, int kidx32) {
+    const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane(((2 * (nt0 + (jn >> 1) * C::WN + wn) + (jn & 1)) * C::KTOT32 + kidx32) * 1024);
+    return *reinterpret_cast<const uint4*>(wbase + soff + lane16);
+  };
   uint4 wsc[SC ? C::KS : 1][SC ? C::NW : 1];
   auto load_weights = [&](int ch) {
+    if constexpr (C::M16) {
+#pragma unroll
+      for (int d = 0; d < PD16; ++d)
+#pragma unroll
+        for (int jn = 0; jn < C::NT16; ++jn) wq16[d][jn] = wload16(jn, ch * NK32 + d);
+      return;
+    }
 #pragma unroll
     for (int d = 0; d < PD; ++d)
 #pragma unroll
@@ -337,6 +379,62 @@ void conv3x3_kernel(ConvArgs a) {
       } else if constexpr (C::SWZ) return smem + (base[i][tap % 3] ^ (ks << 5)) + (tap / 3) * C::RS;
       else return smem + base[i][0] + (tap / 3) * C::RS + (tap % 3) * C::PSTRIDE + ks * 32;
     };
+    if constexpr (C::M16) {
+      // 16x16x32 k-loop: step kk = (tap, s) covers 32 channels; position tile t reads ONE fragment that feeds the wave's NT16
+      // output-channel tiles.  Lane part of the address: one register per tap (GRID) or three VALU operations per tap (DENSE),
+      // XORed with the k-step; tile and tap offsets are immediates.
+      typedef float f32x4v __attribute__((ext_vector_type(4)));
+      const int q16 = lane >> 4;
+      int pl = lane & 15;
+      if constexpr (C::BLK == LANES_DENSE) asm volatile("" : "+v"(pl));
+      auto xaddr16 = [&](int t, int kk) {
+        const int tap = kk / C::KS32, sk = kk % C::KS32, dh = tap / 3, dw = tap % 3;
+        if constexpr (C::BLK == LANES_DENSE) {
+          const int v = (pl * C::CB + ((((pl + dh * (C::WIN + 1) + dw - 1) & 15) ^ q16) << 4)) ^ (sk << 6);
+          return smem + v + (16 * t + dh * (C::WIN + 1) + dw) * C::CB;   // IMG0 = CB: + 1 position
+        } else {
+          const int v = tapreg[NTR == 3 ? dh : 0][dw] ^ ((sk << 6) ^ ((C::GR == 2 && (dh & 1)) ? (16 << C::KRSH) : 0));
+          const int brow = (t / C::MW) * C::GR, bcol = (t % C::MW) * C::GC;   // block origin inside the wave's two block rows
+          if (!C::LEAD && dw == 0 && bcol == 0) return smem + (v + fixreg) + (brow + dh) * C::RS;
+          return smem + v + (C::IMG0 + (bcol + dw - 1) * C::CB + (brow + dh) * C::RS);
+        }
+      };
+      // the position tiles of a k-step are walked in two halves so that only MW fragments are live (registers: 3 workgroups per CU)
+      constexpr int HT = C::MW;
+      uint4 x16[HT];
+#pragma unroll
+      for (int t = 0; t < HT; ++t) x16[t] = *reinterpret_cast<const uint4*>(xaddr16(t, 0));
+      if (!(a.dbg & 2))
+#pragma unroll
+      for (int u = 0; u < 2 * NK32; ++u) {
+        const int kk = u >> 1, t0 = (u & 1) * HT;
+        uint4 wf[C::NT16];
+#pragma unroll
+        for (int jn = 0; jn < C::NT16; ++jn) wf[jn] = wq16[kk % PD16][jn];
+        if ((u & 1) && kk + PD16 < NK32) {   // the ring slot is free once the step's second half has its fragments
+#pragma unroll
+          for (int jn = 0; jn < C::NT16; ++jn) wq16[kk % PD16][jn] = wload16(jn, ch * NK32 + kk + PD16);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < HT; ++t)
+#pragma unroll
+          for (int jn = 0; jn < C::NT16; ++jn) {
+            // accumulator of (position tile t, channel tile jn) = quarter 2 * (t & 1) + (jn & 1) of acc[t / 2][jn / 2]
+            f32x16& A = acc[(t0 + t) >> 1][jn >> 1];
+            const int q0 = 4 * (2 * ((t0 + t) & 1) + (jn & 1));
+            f32x4v part = {A[q0], A[q0 + 1], A[q0 + 2], A[q0 + 3]};
+            part = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[jn]), __builtin_bit_cast(bf16x8, x16[t]), part, 0, 0, 0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) A[q0 + e] = part[e];
+          }
+        if (u + 1 < 2 * NK32) {
+#pragma unroll
+          for (int t = 0; t < HT; ++t) x16[t] = *reinterpret_cast<const uint4*>(xaddr16(((u + 1) & 1) * HT + t, (u + 1) >> 1));
+        }
+      }
+      continue;
+    }
     uint4 xc[C::MW], xn[C::MW];
 #pragma unroll
     for (int i = 0; i < C::MW; ++i) xc[i] = *reinterpret_cast<const uint4*>(xaddr(i, 0));
@@ -420,20 +518,29 @@ void conv3x3_kernel(ConvArgs a) {
 #pragma unroll
       for (int q = 0; q < NPRE; ++q) sreg[q] = fetch_shortcut(q);
     }
+    // The 16 accumulator registers of (M-tile i, channel tile j) are four groups g of 4 consecutive output channels:
+    //   32x32 MFMA: position lane_pos(i, r), channels 8 g + 4 h .. + 3 of the 32-channel tile;
+    //   M16       : quarter g = 2 * (position-tile half) + (channel-tile half): position lane_pos16(2 i + (g >> 1), l & 15),
+    //               channels 16 (g & 1) + 4 (l >> 4) .. + 3.
+    const int p16 = lane & 15, q16 = lane >> 4;
+    auto pos_of = [&](int i, int g) { return C::M16 ? C::lane_pos16(wm, 2 * i + (g >> 1), p16) : C::lane_pos(wm, i, r); };
+    auto coff = [&](int g) { return C::M16 ? 16 * (g & 1) + 4 * q16 : 8 * g + 4 * h; };
+    constexpr int NSUM = C::M16 ? 8 : 16;            // per-lane channel sums of the statistics form
+    auto sidx = [](int g) { return C::M16 ? 4 * (g & 1) : 4 * g; };
     float* sp = nullptr;
-    if constexpr (STATS) sp = se_part + (((size_t)b * tiles + tile) * C::WM + wm) * C::COUT + nbase + 4 * h;
-    float ssum[STATS ? 16 : 1];
+    if constexpr (STATS) sp = se_part + (((size_t)b * tiles + tile) * C::WM + wm) * C::COUT + nbase;
+    float ssum[STATS ? NSUM : 1];
     if constexpr (STATS) {
 #pragma unroll
-      for (int q = 0; q < 16; ++q) ssum[q] = 0.f;
+      for (int q = 0; q < NSUM; ++q) ssum[q] = 0.f;
     }
-    auto ld4 = [&](const float* p, int g) { return *reinterpret_cast<const f32x4*>(p + nbase + 8 * g + 4 * h); };
+    auto ld4 = [&](const float* p, int g) { return *reinterpret_cast<const f32x4*>(p + nbase + coff(g)); };
     const float* gate_b = (RESID || RSC) ? gate + (size_t)b * C::COUT : scale;
     // one (M-tile i, channel group g) cell: 4 values -> BN, gate or ReLU, rounding, plane sums, 8/16 B into the out tile
     auto cell = [&](int i, int g, const f32x4& sc, const f32x4& sh, const f32x4& gt) {
-      const int m = C::lane_pos(wm, i, r);
+      const int m = pos_of(i, g);
       const bool valid = m < mvalid;   // mvalid <= MT
-      unsigned char* lp = smem + m * OPS + (wn * 32 + 4 * h) * C::EB;
+      unsigned char* lp = smem + m * OPS + (wn * 32 + coff(g)) * C::EB;
       const bool store = !C::PARTIAL_M || m < C::MT;
       float v[4];
 #pragma unroll
@@ -443,11 +550,11 @@ void conv3x3_kernel(ConvArgs a) {
         else if (relu) x = relu_nan(x);
         if constexpr (C::EB == 2) x = round_bf16(x);  // what is stored (and what the next conv reads)
         v[q] = x;
-        if constexpr (STATS) ssum[4 * g + q] += valid ? x : 0.f;
+        if constexpr (STATS) ssum[sidx(g) + q] += valid ? x : 0.f;
       }
       if (store) {
-        if constexpr (C::EB == 2) *reinterpret_cast<uint2*>(lp + 8 * g * 2) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
-        else *reinterpret_cast<float4*>(lp + 8 * g * 4) = make_float4(v[0], v[1], v[2], v[3]);
+        if constexpr (C::EB == 2) *reinterpret_cast<uint2*>(lp) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+        else *reinterpret_cast<float4*>(lp) = make_float4(v[0], v[1], v[2], v[3]);
       }
     };
     if constexpr (RSC) {
@@ -458,11 +565,23 @@ void conv3x3_kernel(ConvArgs a) {
       constexpr int KX = CX * C::EB / 32;                                               // k-steps of the 1x1
       const unsigned char* xin = reinterpret_cast<const unsigned char*>(a.sc_in);
       const unsigned char* scb = reinterpret_cast<const unsigned char*>(a.sc_wpack);
-      uint4 wx[KX];
+      constexpr int KX16 = C::M16 ? CX * C::EB / 64 : 1;                                  // M16: 32-channel k-steps of the 1x1
+      uint4 wx[C::M16 ? 1 : KX];
+      uint4 wx16[C::M16 ? 2 : 1][KX16];
+      if constexpr (C::M16) {
 #pragma unroll
-      for (int ks = 0; ks < KX; ++ks) {
-        const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane(((nt0 + j * C::WN + wn) * KX + ks) * 1024);
-        wx[ks] = *reinterpret_cast<const uint4*>(scb + soff + (unsigned)lane * 16u);
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+          for (int sk = 0; sk < KX16; ++sk) {
+            const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane(((2 * (nt0 + j * C::WN + wn) + n) * KX16 + sk) * 1024);
+            wx16[n][sk] = *reinterpret_cast<const uint4*>(scb + soff + (unsigned)lane * 16u);
+          }
+      } else {
+#pragma unroll
+        for (int ks = 0; ks < KX; ++ks) {
+          const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane(((nt0 + j * C::WN + wn) * KX + ks) * 1024);
+          wx[ks] = *reinterpret_cast<const uint4*>(scb + soff + (unsigned)lane * 16u);
+        }
       }
       // x = (bn2(conv2) * gate) + bn_s(conv1x1(x_in)) = k1 * acc + [scale_s folded into the 1x1 weights] + k0 with
       // k1 = scale2 * gate, k0 = shift2 * gate + shift_s: scale the accumulators, let the 1x1's MFMAs accumulate into
@@ -476,6 +595,35 @@ void conv3x3_kernel(ConvArgs a) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) accv[i][j][4 * g + q] *= sc[q] * gt[q];
       }
+      if constexpr (C::M16) {
+        typedef float f32x4v __attribute__((ext_vector_type(4)));
+        auto xload16 = [&](int t, uint4* dst) {   // block-input row of this lane's position: chunk q16 of every 32-channel step
+          const int m = C::lane_pos16(wm, t, p16);
+          const int ho = m / C::WOUT, wo = m % C::WOUT;
+          const unsigned char* xp = xin + ((((size_t)b * a.sc_hin + (size_t)(ho0 + ho) * SS) * (C::WOUT * SS) + wo * SS) * CX) * C::EB + q16 * 16;
+#pragma unroll
+          for (int sk = 0; sk < KX16; ++sk) dst[sk] = (m < mvalid) ? *reinterpret_cast<const uint4*>(xp + sk * 64) : make_uint4(0, 0, 0, 0);
+        };
+        uint4 xf[KX16], xn[KX16];
+        xload16(0, xf);
+#pragma unroll
+        for (int t = 0; t < C::MT16; ++t) {
+          if (t + 1 < C::MT16) xload16(t + 1, xn);
+#pragma unroll
+          for (int sk = 0; sk < KX16; ++sk)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+              f32x16& A = accv[t >> 1][j];
+              const int q0 = 4 * (2 * (t & 1) + n);
+              f32x4v part = {A[q0], A[q0 + 1], A[q0 + 2], A[q0 + 3]};
+              part = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wx16[n][sk]), __builtin_bit_cast(bf16x8, xf[sk]), part, 0, 0, 0);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) A[q0 + e] = part[e];
+            }
+#pragma unroll
+          for (int sk = 0; sk < KX16; ++sk) xf[sk] = xn[sk];
+        }
+      }
       constexpr bool AHEAD = KX <= 4;   // block-input fragments one M-tile ahead of their use
       auto xload = [&](int i, uint4* dst) {
         const int m = C::lane_pos(wm, i, r);
@@ -484,6 +632,7 @@ void conv3x3_kernel(ConvArgs a) {
 #pragma unroll
         for (int ks = 0; ks < KX; ++ks) dst[ks] = (m < mvalid) ? *reinterpret_cast<const uint4*>(xp + ks * 32) : make_uint4(0, 0, 0, 0);
       };
+      if constexpr (!C::M16) {
       uint4 xf[KX], xn[AHEAD ? KX : 1];
       xload(0, xf);
 #pragma unroll
@@ -500,19 +649,20 @@ void conv3x3_kernel(ConvArgs a) {
           }
         }
       }
+      }
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const f32x4 sh = ld4(shift, g), gt = ld4(gate_b, g), h2 = ld4(a.sc_shift, g);
 #pragma unroll
         for (int i = 0; i < C::MW; ++i) {
-          const int m = C::lane_pos(wm, i, r);
-          unsigned char* lp = smem + m * OPS + (wn * 32 + 4 * h) * C::EB;
+          const int m = pos_of(i, g);
+          unsigned char* lp = smem + m * OPS + (wn * 32 + coff(g)) * C::EB;
           float v[4];
 #pragma unroll
           for (int q = 0; q < 4; ++q) v[q] = relu_nan(accv[i][j][4 * g + q] + (sh[q] * gt[q] + h2[q]));
           if (!C::PARTIAL_M || m < C::MT) {
-            if constexpr (C::EB == 2) *reinterpret_cast<uint2*>(lp + 8 * g * 2) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
-            else *reinterpret_cast<float4*>(lp + 8 * g * 4) = make_float4(v[0], v[1], v[2], v[3]);
+            if constexpr (C::EB == 2) *reinterpret_cast<uint2*>(lp) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+            else *reinterpret_cast<float4*>(lp) = make_float4(v[0], v[1], v[2], v[3]);
           }
         }
       }
@@ -544,13 +694,21 @@ void conv3x3_kernel(ConvArgs a) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) cell(i, g, sc[g], sh[g], gt[g]);
     }
-    if constexpr (STATS) {  // sixteen independent DPP reductions after the arithmetic (per-group chains serialised it)
+    if constexpr (STATS && C::M16) {  // a lane's 8 sums belong to its 16-lane row (one row per 4 output channels of each 16-channel tile)
+#pragma unroll
+      for (int q = 0; q < 8; ++q) ssum[q] = row_sum16(ssum[q]);
+      if (p16 == 0) {
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+          *reinterpret_cast<float4*>(sp + 16 * n + 4 * q16) = make_float4(ssum[4 * n], ssum[4 * n + 1], ssum[4 * n + 2], ssum[4 * n + 3]);
+      }
+    } else if constexpr (STATS) {  // sixteen independent DPP reductions after the arithmetic (per-group chains serialised it)
 #pragma unroll
       for (int q = 0; q < 16; ++q) ssum[q] = half_sum_upper_row(ssum[q]);
       if (r == 16) {
 #pragma unroll
         for (int g = 0; g < 4; ++g)
-          *reinterpret_cast<float4*>(sp + 8 * g) = make_float4(ssum[4 * g], ssum[4 * g + 1], ssum[4 * g + 2], ssum[4 * g + 3]);
+          *reinterpret_cast<float4*>(sp + 4 * h + 8 * g) = make_float4(ssum[4 * g], ssum[4 * g + 1], ssum[4 * g + 2], ssum[4 * g + 3]);
       }
     }
     if constexpr (RESID && NPRE < NIT) {  // accumulators are dead: the second half of the shortcut rides out the barrier
@@ -692,17 +850,17 @@ static int launch_cfg(const ConvArgs& a, hipStream_t st) {
 
 // ---- the trunk's convolution shapes ---------------------------------------------------------
 //                      T      CIN COUT S WIN TH WM WN MW NW  CK TAPS
-using B_L1   = ConvCfg<bf16_t,  32,  32, 1, 80,  8, 4, 1, 5, 1, 32, 9, 0, 0, true>;     // two persistent weight-resident workgroups per CU (1 x 16 read-group blocks measured: 333 / 385 vs 336 / 374 us, no gain -- 4.7 LDS cycles per read already)
+using B_L1   = ConvCfg<bf16_t,  32,  32, 1, 80,  8, 4, 1, 5, 1, 32, 9, 0, 0, true, LANES_GRID, true>;     // two persistent weight-resident workgroups per CU; 1 x 16 read-group blocks, 16x16x32 MFMA (310 / 353 vs 324 / 367 us)
 using B_L1S  = ConvCfg<bf16_t,  32,  32, 1, 80,  8, 4, 1, 5, 1, 32, 1, 0, 0, true>;
 using B_L2A  = ConvCfg<bf16_t,  32,  64, 2, 80,  4, 2, 2, 3, 1, 32, 9, 2, 0, true>;     // 4-row tiles (47 KB): two persistent weight-resident WGs/CU instead of one 8-row WG (226 -> 177 us)
 using B_L2S  = ConvCfg<bf16_t,  32,  64, 2, 80,  8, 2, 2, 5, 1, 32, 1, 0, 0, true>;
-using B_L2   = ConvCfg<bf16_t,  64,  64, 1, 40,  8, 2, 2, 5, 1, 64, 9, 3, 4, true, LANES_GRID>;     // three workgroups per CU; 2 x 8 read-group blocks
+using B_L2   = ConvCfg<bf16_t,  64,  64, 1, 40,  8, 2, 2, 5, 1, 64, 9, 3, 4, true, LANES_GRID, true>;     // three workgroups per CU; 2 x 8 read-group blocks
 using B_L3A  = ConvCfg<bf16_t,  64, 128, 2, 40,  4, 1, 4, 3, 1, 64, 9, 2, 0, true>;     // 4-row tiles (47 KB, 80 of 96 M-tile slots): several WGs/CU instead of one (163 -> 127 us)
 using B_L3S  = ConvCfg<bf16_t,  64, 128, 2, 40,  8, 1, 4, 5, 1, 64, 1>;
-using B_L3   = ConvCfg<bf16_t, 128, 128, 1, 20,  8, 1, 4, 5, 1, 128, 9, 3, 4, true, LANES_GRID>;    // three workgroups per CU: 53760 B = 42 LDS granules; 4 x 4 read-group blocks
+using B_L3   = ConvCfg<bf16_t, 128, 128, 1, 20,  8, 1, 4, 5, 1, 128, 9, 3, 4, true, LANES_GRID, true>;    // three workgroups per CU: 53760 B = 42 LDS granules; 4 x 4 read-group blocks
 using B_L4A  = ConvCfg<bf16_t, 128, 256, 2, 20,  8, 1, 4, 3, 1, 64, 9, 2, 0, true>;     // 8-row tiles (46 KB): 147 -> 104 us; NT = 128: grid.y = 2
 using B_L4S  = ConvCfg<bf16_t, 128, 256, 2, 20, 16, 1, 4, 5, 1, 64, 1>;
-using B_L4   = ConvCfg<bf16_t, 256, 256, 1, 10, 17, 1, 4, 6, 1, 128, 9, 2, 0, true, LANES_DENSE>;   // 187 of 192 lane slots enumerate the 17 x 11 padded tile; NT = 128: two workgroups per CU
+using B_L4   = ConvCfg<bf16_t, 256, 256, 1, 10, 17, 1, 4, 6, 1, 128, 9, 2, 0, true, LANES_DENSE, true>;   // 187 of 192 lane slots enumerate the 17 x 11 padded tile; NT = 128: two workgroups per CU
 
 // tuning alternatives kept for A/B runs inside one process (sk_bench_conv shapes 11..14, scripts/conv_bench.py): each is
 // the configuration the product shape above it replaced, with the measured difference at B = 256
@@ -714,11 +872,15 @@ using B_X4   = ConvCfg<bf16_t, 128, 128, 1, 20,  8, 1, 4, 5, 1, 128, 9, 3, 4, tr
 using B_X5   = ConvCfg<bf16_t, 256, 256, 1, 10, 17, 1, 4, 6, 1, 128, 9, 2>;             // L4, linear lane order, padded image (round 1): 10.7 LDS cycles per read
 using B_X6   = ConvCfg<bf16_t,  64,  64, 1, 40,  8, 2, 2, 5, 1, 64, 9, 3, 4, true>;     // L2, linear lane order (round 1)
 using B_X7   = ConvCfg<bf16_t,  32,  32, 1, 80,  8, 4, 1, 5, 1, 32, 9, 0, 0, true>;     // L1, linear lane order (round 1)
+using B_X8   = ConvCfg<bf16_t, 128, 128, 1, 20,  8, 1, 4, 5, 1, 128, 9, 3, 4, true, LANES_GRID>;         // L3, GRID lane order, 32x32x16 MFMA
+using B_X9   = ConvCfg<bf16_t, 256, 256, 1, 10, 17, 1, 4, 6, 1, 128, 9, 2, 0, true, LANES_DENSE>;       // L4, DENSE lane order, 32x32x16 MFMA
+using B_X10  = ConvCfg<bf16_t,  64,  64, 1, 40,  8, 2, 2, 5, 1, 64, 9, 3, 4, true, LANES_GRID>;          // L2, GRID lane order, 32x32x16 MFMA
+using B_X11  = ConvCfg<bf16_t,  32,  32, 1, 80,  8, 4, 1, 5, 1, 32, 9, 0, 0, true, LANES_GRID>;          // L1, GRID lane order, 32x32x16 MFMA
 using F_X0 = ConvCfg<float,  32,  32, 1, 80,  8, 4, 1, 5, 1, 32, 9>;
 using F_X1 = ConvCfg<float,  64,  64, 1, 40,  8, 2, 2, 5, 1, 64, 9>;
 using F_X2 = ConvCfg<float, 128, 128, 1, 20,  8, 1, 4, 5, 1, 128, 9>;
 using F_X3 = ConvCfg<float, 256, 256, 1, 10, 16, 1, 4, 5, 2, 128, 9>;
-using F_X4 = F_X2; using F_X5 = F_X3; using F_X6 = F_X1; using F_X7 = F_X0;
+using F_X4 = F_X2; using F_X5 = F_X3; using F_X6 = F_X1; using F_X7 = F_X0; using F_X8 = F_X2; using F_X9 = F_X3; using F_X10 = F_X1; using F_X11 = F_X0;
 
 using F_L1   = ConvCfg<float,  32,  32, 1, 80,  8, 4, 1, 5, 1, 32, 9, 0, 0, true>;
 using F_L1S  = ConvCfg<float,  32,  32, 1, 80,  8, 4, 1, 5, 1, 32, 1, 0, 0, true>;
@@ -735,13 +897,13 @@ using F_L4   = ConvCfg<float, 256, 256, 1, 10, 16, 1, 4, 5, 2, 128, 9>;
 template <class C>
 static void fill_geom(ConvGeom& g) {
   g.cin = C::CIN; g.cout = C::COUT; g.stride = C::S; g.win = C::WIN; g.th = C::TH; g.wm = C::WM;
-  g.ck = C::CK; g.taps = C::TAPS; g.ks = C::KS; g.eb = C::EB; g.nw = C::NW;
+  g.ck = C::CK; g.taps = C::TAPS; g.ks = C::KS; g.eb = C::EB; g.nw = C::NW; g.m16 = C::M16 ? 1 : 0;
 }
 
 #define SK_CONV_CASES(X) \
   X(CONV_L1, L1) X(CONV_L1S, L1S) X(CONV_L2A, L2A) X(CONV_L2S, L2S) X(CONV_L2, L2) X(CONV_L3A, L3A) \
   X(CONV_L3S, L3S) X(CONV_L3, L3) X(CONV_L4A, L4A) X(CONV_L4S, L4S) X(CONV_L4, L4) \
-  X(11, X0) X(12, X1) X(13, X2) X(14, X3) X(15, X4) X(16, X5) X(17, X6) X(18, X7)
+  X(11, X0) X(12, X1) X(13, X2) X(14, X3) X(15, X4) X(16, X5) X(17, X6) X(18, X7) X(19, X8) X(20, X9) X(21, X10) X(22, X11)
 
 int conv_geom(int shape, int dtype, ConvGeom* g) {
   switch (shape) {
@@ -772,7 +934,26 @@ int launch_conv(int shape, int dtype, const ConvArgs& a, hipStream_t st) {
 //   W[ntile*32 + r][chunk*CK + ks*KE + h*KE/2 + j][tap]      (KE = 32 B / element size)
 size_t conv_pack_bytes(const ConvGeom& g) { return (size_t)g.cout * g.cin * g.taps * g.eb; }
 
+// M16 (bf16 only): fragment (16-channel tile n16, kidx32 = (chunk, tap, s)), lane (r = lane & 15, q = lane >> 4), element j:
+//   W[n16*16 + r][chunk*CK + s*32 + q*8 + j][tap]
 void conv_pack_weights(const ConvGeom& g, const float* w, int kh_kw, void* dst) {
+  if (g.m16) {
+    const int nch = g.cin / g.ck, ks32 = g.ck * g.eb / 64, ktot32 = nch * g.taps * ks32;
+    for (int n16 = 0; n16 < g.cout / 16; ++n16)
+      for (int ch = 0; ch < nch; ++ch)
+        for (int t = 0; t < g.taps; ++t) {
+          const int tap = (g.taps == 9) ? t : (kh_kw == 9 ? 4 : 0);
+          for (int sk = 0; sk < ks32; ++sk) {
+            const size_t kidx = (size_t)(ch * g.taps + t) * ks32 + sk;
+            for (int lane = 0; lane < 64; ++lane)
+              for (int j = 0; j < 8; ++j) {
+                const int co = n16 * 16 + (lane & 15), ci = ch * g.ck + sk * 32 + (lane >> 4) * 8 + j;
+                reinterpret_cast<uint16_t*>(dst)[(((size_t)n16 * ktot32 + kidx) * 64 + lane) * 8 + j] = f32_to_bf16(w[((size_t)co * g.cin + ci) * kh_kw + tap]);
+              }
+          }
+        }
+    return;
+  }
   const int KE = 32 / g.eb, nch = g.cin / g.ck, ktot = nch * g.taps * g.ks;
   for (int nt = 0; nt < g.cout / 32; ++nt)
     for (int ch = 0; ch < nch; ++ch)

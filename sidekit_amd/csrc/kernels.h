@@ -42,7 +42,7 @@ struct ConvArgs {
   int dbg;             // diagnostics only (sk_bench_conv): bit0 skip stores, bit1 skip MFMA loop, bit2 skip staging
 };
 
-struct ConvGeom { int cin, cout, stride, win, th, wm, ck, taps, ks, eb, nw; };
+struct ConvGeom { int cin, cout, stride, win, th, wm, ck, taps, ks, eb, nw; int m16; };   // m16: weights packed for v_mfma_f32_16x16x32_bf16 (16 x 32 fragments)
 
 int conv_geom(int shape, int dtype, ConvGeom* g);
 int launch_conv(int shape, int dtype, const ConvArgs& a, hipStream_t st);

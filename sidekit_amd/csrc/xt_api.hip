@@ -355,8 +355,10 @@ static int finalize_half(xt_handle* h) {
         std::vector<float> wf(w.data.size());
         const size_t per = wf.size() / b.sc.g.cout;
         for (size_t i = 0; i < wf.size(); ++i) wf[i] = w.data[i] * scs[i / per];
-        std::vector<unsigned char> packed(conv_pack_bytes(b.sc.g));
-        conv_pack_weights(b.sc.g, wf.data(), (int)(w.shape[2] * w.shape[3]), packed.data());
+        ConvGeom gs = b.sc.g;           // the fragments conv2's epilogue multiplies with: conv2's MFMA shape, not the stand-alone 1x1 kernel's
+        gs.m16 = b.c2.g.m16;
+        std::vector<unsigned char> packed(conv_pack_bytes(gs));
+        conv_pack_weights(gs, wf.data(), (int)(w.shape[2] * w.shape[3]), packed.data());
         SK_TRY(upload(h, packed.data(), packed.size(), &b.sc_wfold));
       }
       {
