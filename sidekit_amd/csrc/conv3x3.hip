@@ -850,7 +850,7 @@ static int launch_cfg(const ConvArgs& a, hipStream_t st) {
 
 // ---- the trunk's convolution shapes ---------------------------------------------------------
 //                      T      CIN COUT S WIN TH WM WN MW NW  CK TAPS
-using B_L1   = ConvCfg<bf16_t,  32,  32, 1, 80,  8, 4, 1, 5, 1, 32, 9, 0, 0, true, LANES_GRID, true>;     // two persistent weight-resident workgroups per CU; 1 x 16 read-group blocks, 16x16x32 MFMA (310 / 353 vs 324 / 367 us)
+using B_L1   = ConvCfg<bf16_t,  32,  32, 1, 80,  8, 4, 1, 5, 1, 32, 9, 0, 0, true>;     // two persistent weight-resident workgroups per CU; linear lanes + 32x32x16 MFMA kept: HBM-bound, 1 x 16 blocks / 16x16x32 measured no gain in the forward and the A,B,B,A read-group pattern of the 16-lane shape cannot be made conflict-free at 4 slots per position
 using B_L1S  = ConvCfg<bf16_t,  32,  32, 1, 80,  8, 4, 1, 5, 1, 32, 1, 0, 0, true>;
 using B_L2A  = ConvCfg<bf16_t,  32,  64, 2, 80,  4, 2, 2, 3, 1, 32, 9, 2, 0, true>;     // 4-row tiles (47 KB): two persistent weight-resident WGs/CU instead of one 8-row WG (226 -> 177 us)
 using B_L2S  = ConvCfg<bf16_t,  32,  64, 2, 80,  8, 2, 2, 5, 1, 32, 1, 0, 0, true>;
