@@ -144,8 +144,8 @@ __global__ __launch_bounds__(1024) void se_pre_kernel(SeArgs a) {
 #pragma unroll
     for (int v = 0; v < VEC; ++v) m[v] = 0.f;
     const unsigned char* wp = reinterpret_cast<const unsigned char*>(a.w2t) + (size_t)cg * 16;
-#pragma unroll 4
-    for (int k = kg; k < 9 * C; k += KG) {   // k = tap * C + ci
+#pragma unroll 8
+    for (int k = kg; k < 9 * C; k += KG) {   // k = tap * C + ci; eight 16-B weight loads in flight per thread (the loop is L2-latency bound)
       const uint4 w = *reinterpret_cast<const uint4*>(wp + (size_t)k * C * sizeof(WT));
       const float s = S[k];
       const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
@@ -162,18 +162,37 @@ __global__ __launch_bounds__(1024) void se_pre_kernel(SeArgs a) {
 #pragma unroll
     for (int v = 0; v < VEC; ++v) red[kg * C + cg * VEC + v] = m[v];   // KG * C = 1024 * VEC floats
     __syncthreads();
+    // the KG row-group partials of a channel meet in two stages (every thread sums KG / G of them, then G partial sums):
+    // a single thread walking all KG (256 at C = 32) was a serial chain of LDS reads; the order stays fixed
+    {
+      float t = 0.f;
+      for (int q = g; q < KG; q += G) t += red[q * C + c];
+      __syncthreads();
+      red[g * C + c] = t;
+    }
+    __syncthreads();
     if (g == 0) {
       float t = 0.f;
-      for (int q = 0; q < KG; ++q) t += red[q * C + c];
+      for (int q = 0; q < G; ++q) t += red[q * C + c];
       y[c] = t / (float)(hb * a.wout) * a.scale2[c] + a.shift2[c];
     }
   }
   __syncthreads();
   const int R = C / 16;
-  if (threadIdx.x < R) {
-    float s = 0.f;
-    for (int k = 0; k < C; ++k) s = fmaf(a.fc1[threadIdx.x * C + k], y[k], s);
-    hid[threadIdx.x] = relu_nan(s);
+  {  // FC1 (R x C): all threads, thread = (hidden unit r, slice of 16 input channels), slices added in order
+    const int NS = C / 16, r1 = threadIdx.x % R, sl = threadIdx.x / R;   // R * NS = C * C / 256 <= 256 threads
+    if (sl < NS) {
+      float s = 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) s = fmaf(a.fc1[r1 * C + sl * 16 + k], y[sl * 16 + k], s);
+      red[sl * R + r1] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < R) {
+      float s = 0.f;
+      for (int q = 0; q < NS; ++q) s += red[q * R + threadIdx.x];
+      hid[threadIdx.x] = relu_nan(s);
+    }
   }
   __syncthreads();
   if (g == 0) {
