@@ -149,6 +149,10 @@ struct RowSpan {
 int launch_mean_std(const void* x, int x_bf16, long ld, int D, RowSpan rs, float* out, int B, hipStream_t s);
 // attentive statistics: w = softmax_t(e); mu = sum x w; rh = sqrt(clamp(sum x^2 w - mu^2, 1e-9)) (pooling.py:165-168)
 int launch_att_stats(const void* x, int x_bf16, const float* e, long ld, int D, RowSpan rs, float* out, int B, hipStream_t s);
+// bf16 path: attention.4 (h [rows][128] f32 x W2 [D][128] bf16 + b2), softmax over time and the weighted statistics in one kernel:
+// the (rows x D) score matrix e is never written
+int launch_att_fused(const void* x_bf16, const float* h, const void* w2_bf16, const float* b2, long ld, int D, RowSpan rs, float* out, int B,
+                     hipStream_t s);
 // per-(b, column) CMVN over rows: (x - mean) / sqrt(var_biased + eps), in place (InstanceNorm1d)
 int launch_cmvn(float* x, long ld, int D, RowSpan rs, float eps, int B, hipStream_t s);
 // x / ||x||_2 (loss.py:91-100) followed by F.normalize(eps=1e-12) (xvector.py:903)

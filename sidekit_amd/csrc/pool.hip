@@ -162,6 +162,156 @@ int launch_att_stats(const void* x, int x_bf16, const float* e, long ld, int D, 
   return SK_OK;
 }
 
+// ---- attention.4 + softmax over time + weighted statistics in one kernel (bf16 path) ---------------------------------------
+// pooling.py:161-168: e = conv1x1(h) (128 -> D) + bias; w = softmax_t(e); mu = sum_t x w; rh = sqrt(clamp(sum_t x^2 w - mu^2, 1e-9)).
+// The separate form writes e (B*T' x D f32 = 134 MB at B = 256, 4 s) and reads it back twice.  Here the utterance's h rows stream
+// through LDS in chunks of 64 and every 32 x 32 tile of e lives only in the MFMA accumulators (A = h rows so that a lane holds
+// ONE column d and 16 time steps), first to find each column's maximum over time, then -- recomputed, K is only 128 -- for
+// exp / sums.  Same operand rounding and k order as gemm_bf16_kernel, so e is bit-identical to the separate form; only the order
+// of the time sums differs.
+constexpr int AF_LD = 128 * 2 + 16;   // LDS row: 128 bf16 + 16 B pad (conflict-free ds_read_b128 fragments)
+
+// One workgroup = (utterance, 128 columns); each of its four waves owns 32 columns for ALL time steps (two 32-row MFMA tiles per
+// 64-row chunk), keeps its 32 x 128 weight slice in 32 registers for its whole life and never meets the other waves again: the
+// only shared state is the chunk of h rows in LDS.
+__global__ __launch_bounds__(256) void att_fused_kernel(const uint16_t* __restrict__ x, const float* __restrict__ hmat, const uint16_t* __restrict__ w2,
+                                                        const float* __restrict__ b2, long ld, int D, RowSpan rs, float* __restrict__ out) {
+  __shared__ __attribute__((aligned(16))) unsigned char Hs[64 * AF_LD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, hh = lane >> 5;
+  const int b = blockIdx.x, dcol = blockIdx.y * 128 + wave * 32 + r;   // this lane's column
+  const long r0 = rs.row0(b);
+  const int n = rs.count(b);
+  uint4 wreg[8];                                    // B-operand fragments: W2[dcol][16 kk + 8 hh .. + 7]
+#pragma unroll
+  for (int kk = 0; kk < 8; ++kk) wreg[kk] = *reinterpret_cast<const uint4*>(w2 + (long)dcol * 128 + kk * 16 + 8 * hh);
+  const float bias = b2[dcol];
+  auto stage_h = [&](int c0) {                       // h rows c0 .. c0 + 63 (f32) -> bf16 in LDS; rows past the utterance are zero
+    __syncthreads();
+    for (int i = tid; i < 64 * 16; i += 256) {
+      const int row = i >> 4, ch = i & 15;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (c0 + row < n) {
+        const float* p = hmat + (r0 + c0 + row) * 128 + ch * 8;
+        const float4 a = *reinterpret_cast<const float4*>(p), c = *reinterpret_cast<const float4*>(p + 4);
+        v = make_uint4(pack_bf16x2(a.x, a.y), pack_bf16x2(a.z, a.w), pack_bf16x2(c.x, c.y), pack_bf16x2(c.z, c.w));
+      }
+      *reinterpret_cast<uint4*>(Hs + row * AF_LD + ch * 16) = v;
+    }
+    __syncthreads();
+  };
+  auto etile = [&](int mt) {                         // e[t = 32 mt + rowmap][d = dcol] of the staged chunk, bias added
+    f32x16 acc;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+      const uint4 a = *reinterpret_cast<const uint4*>(Hs + (mt * 32 + r) * AF_LD + (kk * 16 + 8 * hh) * 2);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, wreg[kk]), acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] += bias;
+    return acc;
+  };
+  auto trow = [&](int c0, int mt, int q) { return c0 + mt * 32 + (q & 3) + 8 * (q >> 2) + 4 * hh; };
+  if (n <= 64) {
+    // the common case (T' = 51 for 4 s): one chunk -- x values requested first (their HBM latency rides under the staging and the
+    // MFMAs), both e tiles computed once and kept, maximum, weights and sums straight from the accumulators
+    uint16_t xr[2][16];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int t = trow(0, mt, q);
+        xr[mt][q] = x[(r0 + (t < n ? t : n - 1)) * ld + dcol];
+      }
+    stage_h(0);
+    const f32x16 e0 = etile(0), e1 = etile(1);
+    float mx = -INFINITY;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      mx = trow(0, 0, q) < n ? fmaxf(mx, e0[q]) : mx;
+      mx = trow(0, 1, q) < n ? fmaxf(mx, e1[q]) : mx;
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float z = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const float w = trow(0, mt, q) < n ? expf((mt ? e1[q] : e0[q]) - mx) : 0.f;
+        const float xv = bf16_to_f32(xr[mt][q]);
+        z += w;
+        s1 = fmaf(xv, w, s1);
+        s2 = fmaf(xv * xv, w, s2);
+      }
+    z += __shfl_xor(z, 32);
+    s1 += __shfl_xor(s1, 32);
+    s2 += __shfl_xor(s2, 32);
+    if (hh == 0) {
+      const float mu = s1 / z;
+      out[(long)b * 2 * D + dcol] = mu;
+      out[(long)b * 2 * D + D + dcol] = sqrtf(fmaxf(s2 / z - mu * mu, 1e-9f));
+    }
+    return;
+  }
+  // longer utterances -- pass 1: column maxima over the utterance's own rows
+  float mx = -INFINITY;
+  for (int c0 = 0; c0 < n; c0 += 64) {
+    stage_h(c0);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      if (c0 + mt * 32 >= n) break;                  // wave-uniform
+      const f32x16 e = etile(mt);
+#pragma unroll
+      for (int q = 0; q < 16; ++q) mx = trow(c0, mt, q) < n ? fmaxf(mx, e[q]) : mx;
+    }
+  }
+  mx = fmaxf(mx, __shfl_xor(mx, 32));
+  // pass 2: weights and weighted sums (e recomputed: K is only 128)
+  float z = 0.f, s1 = 0.f, s2 = 0.f;
+  for (int c0 = 0; c0 < n; c0 += 64) {
+    stage_h(c0);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      if (c0 + mt * 32 >= n) break;
+      // the tile's 16 x values first, unconditionally (rows past the end re-read the last one): all loads in flight together
+      // instead of one HBM round trip per predicated element
+      uint16_t xr[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int t = trow(c0, mt, q);
+        xr[q] = x[(r0 + (t < n ? t : n - 1)) * ld + dcol];
+      }
+      const f32x16 e = etile(mt);
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const float w = trow(c0, mt, q) < n ? expf(e[q] - mx) : 0.f;
+        const float xv = bf16_to_f32(xr[q]);
+        z += w;
+        s1 = fmaf(xv, w, s1);
+        s2 = fmaf(xv * xv, w, s2);
+      }
+    }
+  }
+  z += __shfl_xor(z, 32);
+  s1 += __shfl_xor(s1, 32);
+  s2 += __shfl_xor(s2, 32);
+  if (hh == 0) {
+    const float mu = s1 / z;
+    out[(long)b * 2 * D + dcol] = mu;
+    out[(long)b * 2 * D + D + dcol] = sqrtf(fmaxf(s2 / z - mu * mu, 1e-9f));
+  }
+}
+
+int launch_att_fused(const void* x_bf16, const float* h, const void* w2_bf16, const float* b2, long ld, int D, RowSpan rs, float* out, int B,
+                     hipStream_t s) {
+  SK_CHECK(D % 128 == 0 && ld >= D, SK_EARG, "att_fused: D=%d must be a multiple of 128", D);
+  hipLaunchKernelGGL(att_fused_kernel, dim3(B, D / 128), dim3(256), 0, s, (const uint16_t*)x_bf16, h, (const uint16_t*)w2_bf16, b2, ld, D, rs, out);
+  SK_HIP(hipGetLastError());
+  return SK_OK;
+}
+
 // CMVN: blockDim = (D, TG); threads with the same x reduce over interleaved rows through LDS.
 __global__ void cmvn_kernel(float* __restrict__ x, long ld, int D, RowSpan rs, float eps) {
   extern __shared__ float red[];

@@ -700,11 +700,15 @@ static int half_from_feats(xt_handle* h, const float* feats, long sb, long sf, l
   g1.M = R; g1.N = 128; g1.K = D; g1.rowbias = (const float*)h->ws_rb.p; g1.rows_per_group = H4;
   g1.act = ACT_RELU_BN_TANH; g1.scale = h->att_bn_scale; g1.shift = h->att_bn_shift; g1.W_bf16 = h->att_w1x_bf16;
   SK_TRY(launch_gemm(g1, st));
+  if (xbf && !getenv("SIDEKIT_AMD_ATT_SEPARATE")) {   // bf16 path: attention.4 + softmax + statistics fused, e never leaves the accumulators
+    SK_TRY(launch_att_fused(X, (const float*)h->ws_h.p, h->att_w2_bf16, h->att_b2, D, D, rs, (float*)h->ws_pooled.p, B, st));
+  } else {
   GemmArgs g2 = gemm_args();  // attention.4
   g2.A = h->ws_h.p; g2.lda = 128; g2.a_rows = R; g2.W = h->att_w2; g2.ldw = 128; g2.C = (float*)h->ws_e.p; g2.ldc = D;
   g2.M = R; g2.N = D; g2.K = 128; g2.bias = h->att_b2; g2.W_bf16 = h->att_w2_bf16;
   SK_TRY(launch_gemm(g2, st));
   SK_TRY(launch_att_stats(X, xbf, (const float*)h->ws_e.p, D, D, rs, (float*)h->ws_pooled.p, B, st));
+  }
   SK_TRY(tap(h, "pooled", h->ws_pooled.p, (size_t)B * 2 * D * 4, st));
   GemmArgs e = gemm_args();  // lin_be + bn_be (xvector.py:578-581)
   e.A = h->ws_pooled.p; e.lda = 2 * D; e.a_rows = B; e.W = h->emb_w; e.ldw = 2 * D; e.C = (float*)h->ws_pre.p;

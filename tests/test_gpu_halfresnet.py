@@ -213,17 +213,23 @@ def test_ab_paths_agree(gpu, monkeypatch):
     wav = 0.1 * torch.randn(3, 30000).cuda()
     lens = [30000, 17000, 22222]
     base = Xtractor(64, model_archi="halfresnet34", loss="aam", seed=5).to(gpu).eval()
-    out = {}
+    long_wav, long_lens = 0.1 * torch.randn(2, 200000).cuda(), [200000, 150001]      # T' = 157 / 118: several 64-row chunks in the fused pooling
+    out, out_long = {}, {}
     for dtype in ("fp32", "bf16"):
         base.compute_dtype = dtype
         out[dtype] = base(wav, is_eval=True, lengths=lens)[1]
-    for var in ("SIDEKIT_AMD_SHORTCUT_TENSOR", "SIDEKIT_AMD_MEL_GEMM"):
+        out_long[dtype] = base(long_wav, is_eval=True, lengths=long_lens)[1]
+    for var in ("SIDEKIT_AMD_SHORTCUT_TENSOR", "SIDEKIT_AMD_MEL_GEMM", "SIDEKIT_AMD_ATT_SEPARATE"):
         monkeypatch.setenv(var, "1")
         alt = Xtractor(64, model_archi="halfresnet34", loss="aam", seed=5).to(gpu).eval()
         for dtype in ("fp32", "bf16"):
             alt.compute_dtype = dtype
             e = alt(wav, is_eval=True, lengths=lens)[1]                 # the switch is read when the native handle is made (first forward)
             assert rel(e, out[dtype]) < (2e-5 if dtype == "fp32" else 2e-2), (var, dtype)
+            if var == "SIDEKIT_AMD_ATT_SEPARATE":   # the fused attention / statistics kernel computes the same scores: only the order of the time sums differs
+                assert rel(e, out[dtype]) < 2e-6, (var, dtype, rel(e, out[dtype]))
+                e_long = alt(long_wav, is_eval=True, lengths=long_lens)[1]
+                assert rel(e_long, out_long[dtype]) < 2e-6, (var, dtype, rel(e_long, out_long[dtype]))
         monkeypatch.delenv(var)
 
 
