@@ -174,9 +174,10 @@ constexpr int AF_LD = 128 * 2 + 16;   // LDS row: 128 bf16 + 16 B pad (conflict-
 // One workgroup = (utterance, 128 columns); each of its four waves owns 32 columns for ALL time steps (two 32-row MFMA tiles per
 // 64-row chunk), keeps its 32 x 128 weight slice in 32 registers for its whole life and never meets the other waves again: the
 // only shared state is the chunk of h rows in LDS.
-__global__ __launch_bounds__(256) void att_fused_kernel(const uint16_t* __restrict__ x, const float* __restrict__ hmat, const uint16_t* __restrict__ w2,
+__global__ __launch_bounds__(256, 4) void att_fused_kernel(const uint16_t* __restrict__ x, const float* __restrict__ hmat, const uint16_t* __restrict__ w2,
                                                         const float* __restrict__ b2, long ld, int D, RowSpan rs, float* __restrict__ out) {
   __shared__ __attribute__((aligned(16))) unsigned char Hs[64 * AF_LD];
+  __shared__ __attribute__((aligned(16))) unsigned char Xs[64 * AF_LD];   // the chunk's x[.., 128 columns] (bf16), same row pitch
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, hh = lane >> 5;
   const int b = blockIdx.x, dcol = blockIdx.y * 128 + wave * 32 + r;   // this lane's column
@@ -186,10 +187,23 @@ __global__ __launch_bounds__(256) void att_fused_kernel(const uint16_t* __restri
 #pragma unroll
   for (int kk = 0; kk < 8; ++kk) wreg[kk] = *reinterpret_cast<const uint4*>(w2 + (long)dcol * 128 + kk * 16 + 8 * hh);
   const float bias = b2[dcol];
-  auto stage_h = [&](int c0) {                       // h rows c0 .. c0 + 63 (f32) -> bf16 in LDS; rows past the utterance are zero
+  // rows c0 .. c0 + 63 of the utterance: h (f32 -> bf16) and, when asked, the workgroup's 128 columns of x, both as 16-byte
+  // coalesced requests issued together; rows past the utterance are zero.  (x read per lane straight from HBM is one 2-byte
+  // request per element with a 64-bit address each: 168 registers, three workgroups per CU.)
+  auto stage = [&](int c0, bool with_x) {
     __syncthreads();
-    for (int i = tid; i < 64 * 16; i += 256) {
-      const int row = i >> 4, ch = i & 15;
+    uint4 xv[4];
+    if (with_x) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int i = tid + 256 * k, row = i >> 4, ch = i & 15;
+        xv[k] = make_uint4(0, 0, 0, 0);
+        if (c0 + row < n) xv[k] = *reinterpret_cast<const uint4*>(x + (r0 + c0 + row) * ld + blockIdx.y * 128 + ch * 8);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int i = tid + 256 * k, row = i >> 4, ch = i & 15;
       uint4 v = make_uint4(0, 0, 0, 0);
       if (c0 + row < n) {
         const float* p = hmat + (r0 + c0 + row) * 128 + ch * 8;
@@ -197,6 +211,13 @@ __global__ __launch_bounds__(256) void att_fused_kernel(const uint16_t* __restri
         v = make_uint4(pack_bf16x2(a.x, a.y), pack_bf16x2(a.z, a.w), pack_bf16x2(c.x, c.y), pack_bf16x2(c.z, c.w));
       }
       *reinterpret_cast<uint4*>(Hs + row * AF_LD + ch * 16) = v;
+    }
+    if (with_x) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int i = tid + 256 * k, row = i >> 4, ch = i & 15;
+        *reinterpret_cast<uint4*>(Xs + row * AF_LD + ch * 16) = xv[k];
+      }
     }
     __syncthreads();
   };
@@ -213,84 +234,55 @@ __global__ __launch_bounds__(256) void att_fused_kernel(const uint16_t* __restri
     for (int q = 0; q < 16; ++q) acc[q] += bias;
     return acc;
   };
-  auto trow = [&](int c0, int mt, int q) { return c0 + mt * 32 + (q & 3) + 8 * (q >> 2) + 4 * hh; };
+  auto lrow = [&](int mt, int q) { return mt * 32 + (q & 3) + 8 * (q >> 2) + 4 * hh; };   // chunk row of accumulator element q
+  const unsigned char* xcol = Xs + (wave * 32 + r) * 2;
+  float z = 0.f, s1 = 0.f, s2 = 0.f;
+  auto accumulate = [&](const f32x16& e, int c0, int mt, float mx) {   // weights and weighted sums of one e tile
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int lr = lrow(mt, q);
+      const float w = c0 + lr < n ? expf(e[q] - mx) : 0.f;
+      const float xv = bf16_to_f32(*reinterpret_cast<const uint16_t*>(xcol + lr * AF_LD));
+      z += w;
+      s1 = fmaf(xv, w, s1);
+      s2 = fmaf(xv * xv, w, s2);
+    }
+  };
   if (n <= 64) {
-    // the common case (T' = 51 for 4 s): one chunk -- x values requested first (their HBM latency rides under the staging and the
-    // MFMAs), both e tiles computed once and kept, maximum, weights and sums straight from the accumulators
-    uint16_t xr[2][16];
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const int t = trow(0, mt, q);
-        xr[mt][q] = x[(r0 + (t < n ? t : n - 1)) * ld + dcol];
-      }
-    stage_h(0);
+    // the common case (T' = 51 for 4 s): one chunk, both e tiles computed once and kept: maximum, weights and sums straight from
+    // the accumulators
+    stage(0, true);
     const f32x16 e0 = etile(0), e1 = etile(1);
     float mx = -INFINITY;
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
-      mx = trow(0, 0, q) < n ? fmaxf(mx, e0[q]) : mx;
-      mx = trow(0, 1, q) < n ? fmaxf(mx, e1[q]) : mx;
+      mx = lrow(0, q) < n ? fmaxf(mx, e0[q]) : mx;
+      mx = lrow(1, q) < n ? fmaxf(mx, e1[q]) : mx;
     }
     mx = fmaxf(mx, __shfl_xor(mx, 32));
-    float z = 0.f, s1 = 0.f, s2 = 0.f;
+    accumulate(e0, 0, 0, mx);
+    accumulate(e1, 0, 1, mx);
+  } else {
+    // longer utterances -- pass 1: column maxima over the utterance's own rows
+    float mx = -INFINITY;
+    for (int c0 = 0; c0 < n; c0 += 64) {
+      stage(c0, false);
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+      for (int mt = 0; mt < 2; ++mt) {
+        if (c0 + mt * 32 >= n) break;                  // wave-uniform
+        const f32x16 e = etile(mt);
 #pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const float w = trow(0, mt, q) < n ? expf((mt ? e1[q] : e0[q]) - mx) : 0.f;
-        const float xv = bf16_to_f32(xr[mt][q]);
-        z += w;
-        s1 = fmaf(xv, w, s1);
-        s2 = fmaf(xv * xv, w, s2);
+        for (int q = 0; q < 16; ++q) mx = c0 + lrow(mt, q) < n ? fmaxf(mx, e[q]) : mx;
       }
-    z += __shfl_xor(z, 32);
-    s1 += __shfl_xor(s1, 32);
-    s2 += __shfl_xor(s2, 32);
-    if (hh == 0) {
-      const float mu = s1 / z;
-      out[(long)b * 2 * D + dcol] = mu;
-      out[(long)b * 2 * D + D + dcol] = sqrtf(fmaxf(s2 / z - mu * mu, 1e-9f));
     }
-    return;
-  }
-  // longer utterances -- pass 1: column maxima over the utterance's own rows
-  float mx = -INFINITY;
-  for (int c0 = 0; c0 < n; c0 += 64) {
-    stage_h(c0);
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    // pass 2: weights and weighted sums (e recomputed: K is only 128)
+    for (int c0 = 0; c0 < n; c0 += 64) {
+      stage(c0, true);
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-      if (c0 + mt * 32 >= n) break;                  // wave-uniform
-      const f32x16 e = etile(mt);
-#pragma unroll
-      for (int q = 0; q < 16; ++q) mx = trow(c0, mt, q) < n ? fmaxf(mx, e[q]) : mx;
-    }
-  }
-  mx = fmaxf(mx, __shfl_xor(mx, 32));
-  // pass 2: weights and weighted sums (e recomputed: K is only 128)
-  float z = 0.f, s1 = 0.f, s2 = 0.f;
-  for (int c0 = 0; c0 < n; c0 += 64) {
-    stage_h(c0);
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-      if (c0 + mt * 32 >= n) break;
-      // the tile's 16 x values first, unconditionally (rows past the end re-read the last one): all loads in flight together
-      // instead of one HBM round trip per predicated element
-      uint16_t xr[16];
-#pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const int t = trow(c0, mt, q);
-        xr[q] = x[(r0 + (t < n ? t : n - 1)) * ld + dcol];
-      }
-      const f32x16 e = etile(mt);
-#pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const float w = trow(c0, mt, q) < n ? expf(e[q] - mx) : 0.f;
-        const float xv = bf16_to_f32(xr[q]);
-        z += w;
-        s1 = fmaf(xv, w, s1);
-        s2 = fmaf(xv * xv, w, s2);
+      for (int mt = 0; mt < 2; ++mt) {
+        if (c0 + mt * 32 >= n) break;
+        accumulate(etile(mt), c0, mt, mx);
       }
     }
   }
