@@ -120,10 +120,11 @@ int launch_gemm(const GemmArgs& g, hipStream_t s);
 struct FftArgs {
   const float* wav; long wav_ld;
   const int* nsamples; int nsamples_uniform;   // per-utterance sample counts (device) or one value for all
-  const float* window;                         // [400]
-  const float* tw512;                          // exp(-2 pi i m / 512),  m = 0..511, interleaved (re, im)
-  const float* tw1024;                         // exp(-2 pi i k / 1024), k = 0..512
-  float* P; long ldp;                          // [M][ldp] power spectrum, ldp >= 513 (extra columns zeroed)
+  int n_fft;                                   // 1024 (window 400, log-mel front-end) or 2048 (window 1024, MFCC front-end)
+  const float* window;                         // [400] / [1024]
+  const float* tw512;                          // exp(-2 pi i m / (n_fft/2)), m = 0..n_fft/2-1, interleaved (re, im): the complex transform's twiddles
+  const float* tw1024;                         // exp(-2 pi i k / n_fft),     k = 0..n_fft/2: the real-FFT split's
+  float* P; long ldp;                          // [M][ldp] power spectrum, ldp >= n_fft/2 + 1 (extra columns zeroed)
   int M, t_max, hop;
   const int* row_b; const int* row_t;          // optional ragged row map
   float preemph;

@@ -73,6 +73,7 @@ using namespace sk;
 struct xt_handle {
   bool shortcut_tensor = getenv("SIDEKIT_AMD_SHORTCUT_TENSOR") != nullptr;   // A/B switch, see half_from_feats
   bool mel_gemm = getenv("SIDEKIT_AMD_MEL_GEMM") != nullptr;                 // A/B switch: mel projection as a separate GEMM
+  bool mfcc_dft_gemm = getenv("SIDEKIT_AMD_MFCC_DFT_GEMM") != nullptr;       // A/B switch: MFCC spectrum as a DFT contraction (round-1 form) instead of the FFT
   xt_config cfg;
   int device = 0;
   bool finalized = false;
@@ -87,8 +88,8 @@ struct xt_handle {
   float* d_fbT = nullptr;    // [n_mels][nbp]
   float* d_mel_w = nullptr; int* d_mel_start = nullptr; int* d_mel_len = nullptr; bool mel_fused = false;   // compacted bank (frontend_fft.hip)
   float* d_dctT = nullptr;   // [n_out][n_mels] (MFCC)
-  float* d_tw512 = nullptr;  // FFT twiddles (log-mel front-end)
-  float* d_tw1024 = nullptr;
+  float* d_tw512 = nullptr;  // FFT twiddles: the n_fft/2-point complex transform's ...
+  float* d_tw1024 = nullptr; // ... and the real-FFT split's
 
   // halfresnet34
   void* d_zeros = nullptr;
@@ -271,7 +272,7 @@ static int build_frontend(xt_handle* h) {
   for (int j = 0; j < nb; ++j)
     for (int m = 0; m < f.n_mels; ++m) fbT[(size_t)m * h->nbp + j] = fb[(size_t)j * f.n_mels + m];
   SK_TRY(upload_f(h, fbT, &h->d_fbT));
-  if (mel) {  // compacted filters for the projection fused into the FFT kernel: filter j = bins [start, start + len)
+  {  // compacted filters for the projection fused into the FFT kernel: filter j = bins [start, start + len)
     std::vector<int> st(f.n_mels, 0), ln(f.n_mels, 0);
     int maxlen = 0;
     for (int m = 0; m < f.n_mels; ++m) {
@@ -291,12 +292,15 @@ static int build_frontend(xt_handle* h) {
       SK_TRY(upload(h, ln.data(), ln.size() * sizeof(int), (void**)&h->d_mel_len));
     }
   }
-  if (mel) {  // twiddles of the 1024-point real FFT (frontend_fft.hip), rounded once from double
-    std::vector<float> t512(2 * 512), t1024(2 * 513);
-    for (int m = 0; m < 512; ++m) { t512[2 * m] = (float)cos(2.0 * M_PI * m / 512.0); t512[2 * m + 1] = (float)(-sin(2.0 * M_PI * m / 512.0)); }
-    for (int k = 0; k <= 512; ++k) { t1024[2 * k] = (float)cos(2.0 * M_PI * k / 1024.0); t1024[2 * k + 1] = (float)(-sin(2.0 * M_PI * k / 1024.0)); }
-    SK_TRY(upload_f(h, t512, &h->d_tw512));
-    SK_TRY(upload_f(h, t1024, &h->d_tw1024));
+  {  // twiddles of the n_fft-point real FFT (frontend_fft.hip), rounded once from double: the n_fft/2-point complex transform's
+     // and the real-FFT split's
+    SK_CHECK((f.n_fft == 1024 && f.win == 400) || (f.n_fft == 2048 && f.win == 1024), SK_EARG, "front-end FFT: n_fft %d / window %d unsupported", f.n_fft, f.win);
+    const int nh = f.n_fft / 2;
+    std::vector<float> tc(2 * (size_t)nh), ts(2 * (size_t)(nh + 1));
+    for (int m = 0; m < nh; ++m) { tc[2 * m] = (float)cos(2.0 * M_PI * m / nh); tc[2 * m + 1] = (float)(-sin(2.0 * M_PI * m / nh)); }
+    for (int k = 0; k <= nh; ++k) { ts[2 * k] = (float)cos(2.0 * M_PI * k / f.n_fft); ts[2 * k + 1] = (float)(-sin(2.0 * M_PI * k / f.n_fft)); }
+    SK_TRY(upload_f(h, tc, &h->d_tw512));
+    SK_TRY(upload_f(h, ts, &h->d_tw1024));
   }
   if (!mel) {
     const auto& dct = T(h, "preprocessor.MFCC.dct_mat");  // [n_mels][n_out]
@@ -544,10 +548,14 @@ static int ring_end(xt_handle* h, hipStream_t st) {
 static int frontend_rows(xt_handle* h, const float* d_wav, int64_t wav_ld, const BatchMeta& m, float* d_feat_rows, hipStream_t st) {
   const FrontCfg& f = h->fc;
   const int M = m.R ? m.R : m.B * m.T;
+  const bool mfcc = h->cfg.arch == XT_ARCH_TDNN;
+  float* logmel = mfcc ? (float*)h->ws_act[3].p : d_feat_rows;   // MFCC: the DCT follows
   GemmArgs p = gemm_args();
-  if (h->cfg.arch == XT_ARCH_HALFRESNET34) {
+  bool have_logmel = false;
+  if (!(mfcc && h->mfcc_dft_gemm)) {
     // 1) |rFFT(window * preemph(frame))|^2, one wavefront per frame (frontend_fft.hip)
     FftArgs fa;
+    fa.n_fft = f.n_fft;
     fa.wav = d_wav; fa.wav_ld = wav_ld; fa.nsamples = m.d_nsamples; fa.nsamples_uniform = m.nsamples_uniform; fa.window = h->d_window;
     fa.tw512 = h->d_tw512; fa.tw1024 = h->d_tw1024; fa.P = (float*)h->ws_S.p; fa.ldp = h->nbp; fa.M = M; fa.t_max = m.T; fa.hop = f.hop;
     fa.row_b = m.d_row_b; fa.row_t = m.d_row_t; fa.preemph = 0.97f;
@@ -555,17 +563,14 @@ static int frontend_rows(xt_handle* h, const float* d_wav, int64_t wav_ld, const
     fa.mel_w = nullptr; fa.mel_start = nullptr; fa.mel_len = nullptr; fa.n_mels = 0; fa.logmel = nullptr; fa.ldl = 0;
     if (h->mel_fused && !h->mel_gemm) {  // power spectrum stays in LDS, the kernel writes log-mel rows
       fa.mel_w = h->d_mel_w; fa.mel_start = h->d_mel_start; fa.mel_len = h->d_mel_len; fa.n_mels = f.n_mels;
-      fa.logmel = d_feat_rows; fa.ldl = f.n_mels;
-      { ProfScope ps(h, XT_PROF_FRONTEND, st); SK_TRY(launch_stft_power_fft(fa, st)); }
-      RowSpan rs{m.d_offsets, m.T, m.lens, 0, 0};
-      { ProfScope ps(h, XT_PROF_FRONTEND, st); SK_TRY(launch_cmvn(d_feat_rows, f.n_out, f.n_out, rs, 1e-5f, m.B, st)); }
-      return SK_OK;
+      fa.logmel = logmel; fa.ldl = f.n_mels;
+      have_logmel = true;
     }
     { ProfScope ps(h, XT_PROF_FRONTEND, st); SK_TRY(launch_stft_power_fft(fa, st)); }
     // 2) power x mel filterbank, log(. + 1e-6)
     p.a_mode = A_PLAIN; p.A = h->ws_S.p; p.lda = h->nbp; p.a_rows = M;
   } else {
-    // 1) frames x DFT basis -> [re | im]   (MFCC front-end: n_fft 2048, win 1024)
+    // 1) frames x DFT basis -> [re | im]   (A/B form of the MFCC front-end: n_fft 2048, win 1024)
     GemmArgs g = gemm_args();
     g.a_mode = A_FRAMES; g.A = d_wav; g.wav_ld = wav_ld; g.window = h->d_window; g.nsamples = m.d_nsamples;
     g.nsamples_uniform = m.nsamples_uniform; g.hop = f.hop; g.t_max = m.T; g.row_b = m.d_row_b; g.row_t = m.d_row_t;
@@ -576,11 +581,11 @@ static int frontend_rows(xt_handle* h, const float* d_wav, int64_t wav_ld, const
     // 2) |.|^2 x mel filterbank, log(. + 1e-6)
     p.a_mode = A_POWER; p.A = h->ws_S.p; p.lda = 2 * h->nbp; p.kc = h->nbp;
   }
-  p.W = h->d_fbT; p.ldw = h->nbp; p.M = M; p.N = f.n_mels; p.K = h->nbp; p.act = ACT_LOG_EPS;
-  const bool mfcc = h->cfg.arch == XT_ARCH_TDNN;
-  float* logmel = mfcc ? (float*)h->ws_act[3].p : d_feat_rows;
-  p.C = logmel; p.ldc = f.n_mels;
-  { ProfScope ps(h, XT_PROF_FRONTEND, st); SK_TRY(launch_gemm(p, st)); }
+  if (!have_logmel) {
+    p.W = h->d_fbT; p.ldw = h->nbp; p.M = M; p.N = f.n_mels; p.K = h->nbp; p.act = ACT_LOG_EPS;
+    p.C = logmel; p.ldc = f.n_mels;
+    { ProfScope ps(h, XT_PROF_FRONTEND, st); SK_TRY(launch_gemm(p, st)); }
+  }
   if (mfcc) {  // 3) DCT-II (ortho) 100 -> 80
     GemmArgs d = gemm_args();
     d.a_mode = A_PLAIN; d.A = logmel; d.lda = f.n_mels; d.a_rows = M; d.W = h->d_dctT; d.ldw = f.n_mels;

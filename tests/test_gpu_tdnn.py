@@ -79,3 +79,25 @@ def test_wav_variable_length_batch(gpu, fx):
             m(wav[:1].cuda(), is_eval=True)
         finally:
             m.compute_dtype = None
+
+
+def test_mfcc_fft_matches_the_dft_contraction(gpu, fx, monkeypatch):
+    """The MFCC spectrum as a 2048-point real FFT (frontend_fft.hip) against the round-1 form, a (frames x 1024) x (1024 x 2050)
+    DFT contraction on the exact-f32 matrix cores (SIDEKIT_AMD_MFCC_DFT_GEMM=1), and both against the oracle: ragged lengths
+    with reflect-padded edges, features after CMVN."""
+    lens = [16000 + 17, 40000, 14 * 512 + 5, 64000]       # incl. the shortest utterance the TDNN context admits (15 frames)
+    torch.manual_seed(9)
+    wav = 0.1 * torch.randn(len(lens), max(lens))
+    m_fft = _model(gpu, fx, "aam")
+    monkeypatch.setenv("SIDEKIT_AMD_MFCC_DFT_GEMM", "1")
+    m_dft = _model(gpu, fx, "aam")
+    monkeypatch.delenv("SIDEKIT_AMD_MFCC_DFT_GEMM")
+    for i, n in enumerate(lens):
+        ref = ofe.mfcc_frontend(wav[i:i + 1, :n])
+        a = m_fft.features(wav[i:i + 1, :n].cuda())
+        b = m_dft.features(wav[i:i + 1, :n].cuda())
+        assert a.shape == ref.shape and rel(a, ref) < TOL and rel(b, ref) < TOL and rel(a, b) < TOL, (i, n)
+    fa = m_fft.features(wav.cuda(), lengths=lens)         # the same utterances as one ragged batch
+    for i, n in enumerate(lens):
+        t = 1 + n // 512
+        assert rel(fa[i, :, :t], ofe.mfcc_frontend(wav[i:i + 1, :n])[0]) < TOL, (i, n)
