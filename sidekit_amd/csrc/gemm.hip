@@ -105,33 +105,45 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
                                    : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
-  f32x16 acc;
+  // K is cut into g.kslices slices of whole k-tiles and a result is ALWAYS 0 + slice 0 + slice 1 + ... (each slice an FMA chain
+  // from zero), whether the slices run as blockIdx.z (small M: parallelism; gemm_splitk_epilogue_kernel adds them) or one after the
+  // other in this workgroup (large M) -- an utterance's embedding does not depend on how many others share its batch.
+  f32x16 acc, tot;
 #pragma unroll
-  for (int q = 0; q < 16; ++q) acc[q] = 0.f;
-  // split-K: blockIdx.z owns k-tiles [kt0, kt1)
+  for (int q = 0; q < 16; ++q) tot[q] = 0.f;
   const int nk_all = (g.K + BK - 1) / BK;
-  const int per = (nk_all + g.ksplit - 1) / g.ksplit;
-  const int kt0 = blockIdx.z * per, kt1 = (kt0 + per < nk_all) ? kt0 + per : nk_all;
-  if (kt0 < kt1) fetch(kt0 * BK);
-  for (int kt = kt0; kt < kt1; ++kt) {
+  const int per = (nk_all + g.kslices - 1) / g.kslices;
+  const int z0 = g.ksplit > 1 ? (int)blockIdx.z : 0, z1 = g.ksplit > 1 ? z0 + 1 : g.kslices;
+  for (int z = z0; z < z1; ++z) {
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      *reinterpret_cast<float4*>(&As[(srow + q * 32) * LDT + sk4]) = ra[q];
-      *reinterpret_cast<float4*>(&Ws[(srow + q * 32) * LDT + sk4]) = rw[q];
-    }
-    __syncthreads();
-    if (kt + 1 < kt1) fetch((kt + 1) * BK);
+    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+    const int kt0 = z * per, kt1 = (kt0 + per < nk_all) ? kt0 + per : nk_all;
+    if (kt0 < kt1) fetch(kt0 * BK);
+    for (int kt = kt0; kt < kt1; ++kt) {
 #pragma unroll
-    for (int kk = 0; kk < BK; kk += 8) {
-      const float4 a = *reinterpret_cast<const float4*>(&As[(wm * 32 + r) * LDT + kk + 4 * h]);
-      const float4 b = *reinterpret_cast<const float4*>(&Ws[(wn * 32 + r) * LDT + kk + 4 * h]);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+      for (int q = 0; q < 2; ++q) {
+        *reinterpret_cast<float4*>(&As[(srow + q * 32) * LDT + sk4]) = ra[q];
+        *reinterpret_cast<float4*>(&Ws[(srow + q * 32) * LDT + sk4]) = rw[q];
+      }
+      __syncthreads();
+      if (kt + 1 < kt1) fetch((kt + 1) * BK);
+#pragma unroll
+      for (int kk = 0; kk < BK; kk += 8) {
+        const float4 a = *reinterpret_cast<const float4*>(&As[(wm * 32 + r) * LDT + kk + 4 * h]);
+        const float4 b = *reinterpret_cast<const float4*>(&Ws[(wn * 32 + r) * LDT + kk + 4 * h]);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+      }
+      __syncthreads();
     }
-    __syncthreads();
+    if (g.ksplit == 1 && g.kslices > 1) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) tot[q] += acc[q];
+    }
   }
+  if (g.ksplit == 1 && g.kslices > 1) acc = tot;
   // epilogue: D[row = (q&3) + 8*(q>>2) + 4*h][col = r]
   const int n = n0 + wn * 32 + r;
   if (n >= g.N) return;
@@ -224,10 +236,11 @@ __global__ __launch_bounds__(256) void gemm_splitk_epilogue_kernel(GemmArgs g) {
 
 int launch_gemm(const GemmArgs& g_in, hipStream_t s) {
   GemmArgs g = g_in;
-  g.ksplit = 1;
-  if (g.splitk_ws && g.M <= 512 && g.K >= 1024) {
+  g.ksplit = 1; g.kslices = 1;
+  if (g.splitk_ws && g.K >= 1024) {   // the summation order depends on K alone; M only decides where the slices run
     const int nk = (g.K + BK - 1) / BK;
-    g.ksplit = nk / 8 < 32 ? (nk / 8 > 1 ? nk / 8 : 1) : 32;   // >= 8 k-tiles per slice, at most 32 slices
+    g.kslices = nk / 8 < 32 ? (nk / 8 > 1 ? nk / 8 : 1) : 32;   // >= 8 k-tiles per slice, at most 32 slices
+    if (g.M <= 512) g.ksplit = g.kslices;
   }
   SK_CHECK(g.M > 0 && g.N > 0 && g.K > 0, SK_EARG, "gemm: empty problem %dx%dx%d", g.M, g.N, g.K);
   SK_CHECK(g.K % 4 == 0 && g.ldw % 4 == 0, SK_EARG, "gemm: K=%d / ldw=%ld must be multiples of 4", g.K, g.ldw);

@@ -109,8 +109,9 @@ struct GemmArgs {
   // split-K for skinny problems (M <= 512, K large: 16 workgroups would otherwise walk thousands of k-steps serially):
   const void* W_bf16;   // optional bf16 copy of W ([N][K], ldw elements): with a_mode == A_PLAIN and K % 8 == 0 the product runs on the
                         // bf16 MFMA (operands rounded to bf16, f32 accumulate) -- used by the bf16 compute path only
-  float* splitk_ws;     // [ksplit][M][N] partial sums, or null (no split)
-  int ksplit;           // set by launch_gemm
+  float* splitk_ws;     // [ksplit][M][N] partial sums (M <= 512), or null: plain k order.  Non-null selects the sliced summation order for every M
+  int ksplit;           // set by launch_gemm: slices run as blockIdx.z (1: inside the workgroup)
+  int kslices;          // set by launch_gemm: slices the K range is summed in (a function of K alone)
 };
 GemmArgs gemm_args();   // zero-initialised, alpha = 1
 int launch_gemm(const GemmArgs& g, hipStream_t s);

@@ -248,3 +248,16 @@ def test_profile_slots(model):
     model.set_profile(False)
     model(wav, is_eval=True)
     assert model.get_profile(reset=True) == {}
+
+
+def test_embedding_does_not_depend_on_the_batch_size(gpu):
+    """An utterance's embedding is bit-identical whether 7, 256 or 600 utterances share its batch: the embedding GEMMs cut K
+    into the same slices for every M (above 512 rows the slices run inside the workgroup instead of as blockIdx.z)."""
+    m = Xtractor(7205, model_archi="halfresnet34", loss="aam", seed=77).to(gpu).eval()
+    g = torch.Generator(device="cuda").manual_seed(5)
+    wav = 0.1 * torch.randn(600, 16000, device="cuda", generator=g)
+    for dt in ("fp32", "bf16"):
+        m.compute_dtype = dt
+        big = m(wav, is_eval=True)[1]
+        parts = torch.cat([m(wav[:7], is_eval=True)[1], m(wav[7:263], is_eval=True)[1], m(wav[263:], is_eval=True)[1]])
+        assert torch.equal(big, parts), (dt, float((big - parts).abs().max()))
