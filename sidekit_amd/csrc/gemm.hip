@@ -162,6 +162,103 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   }
 }
 
+// ---- 128 x 128 tile for the large problems (TDNN layers: 96k rows x 512..1536; 16k x 16k cosine trial matrices) -------------
+// With 64 x 64 tiles every k-tile moves 16 KB of operands for 262 kFLOP: 16 FLOP/B, i.e. 6 TB/s of L2 traffic at the 96 TFLOP/s
+// the kernel reached (61 % of the f32 MFMA peak).  Four waves of 64 x 64 (2 x 2 accumulator tiles, 64 registers) halve that.
+// Each output element sees the same k-ordered FMA chain as in the 64 x 64 kernel: results are bit-identical.
+constexpr int BM2 = 128, BN2 = 128;
+
+template <class LA, bool SLICED>
+__global__ __launch_bounds__(256, 2) void gemm128_kernel(GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) float As[BM2 * LDT];
+  __shared__ __attribute__((aligned(16))) float Ws[BN2 * LDT];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.x * BM2, n0 = blockIdx.y * BN2;
+  const int srow = tid >> 3, sk4 = (tid & 7) * 4;
+  float4 ra[4], rw[4];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int row = srow + q * 32;
+      ra[q] = LA::load(g, m0 + row, k0 + sk4);
+      const int n = n0 + row, k = k0 + sk4;
+      rw[q] = (n < g.N && k < g.K) ? *reinterpret_cast<const float4*>(g.W + (long)n * g.ldw + k)
+                                   : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  f32x16 acc[2][2], tot[SLICED ? 2 : 1][SLICED ? 2 : 1];
+  if constexpr (SLICED) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) tot[i][j][q] = 0.f;
+  }
+  const int nk_all = (g.K + BK - 1) / BK;
+  const int nz = SLICED ? g.kslices : 1, per = (nk_all + nz - 1) / nz;
+  for (int z = 0; z < nz; ++z) {   // same slice order as gemm_kernel
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+    const int kt0 = z * per, kt1 = (kt0 + per < nk_all) ? kt0 + per : nk_all;
+    if (kt0 < kt1) fetch(kt0 * BK);
+    for (int kt = kt0; kt < kt1; ++kt) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        *reinterpret_cast<float4*>(&As[(srow + q * 32) * LDT + sk4]) = ra[q];
+        *reinterpret_cast<float4*>(&Ws[(srow + q * 32) * LDT + sk4]) = rw[q];
+      }
+      __syncthreads();
+      if (kt + 1 < kt1) fetch((kt + 1) * BK);
+#pragma unroll
+      for (int kk = 0; kk < BK; kk += 8) {
+        float4 a[2], b[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          a[i] = *reinterpret_cast<const float4*>(&As[(wm * 64 + i * 32 + r) * LDT + kk + 4 * h]);
+          b[i] = *reinterpret_cast<const float4*>(&Ws[(wn * 64 + i * 32 + r) * LDT + kk + 4 * h]);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
+          }
+      }
+      __syncthreads();
+    }
+    if constexpr (SLICED) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int q = 0; q < 16; ++q) tot[i][j][q] += acc[i][j][q];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = n0 + wn * 64 + j * 32 + r;
+      if (n >= g.N) continue;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int m = m0 + wm * 64 + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+        if (m < g.M) g.C[(long)m * g.ldc + n] = gemm_epilogue(g, SLICED ? tot[SLICED ? i : 0][SLICED ? j : 0][q] : acc[i][j][q], m, n);
+      }
+    }
+}
+
 // ---- bf16 form: same 64x64 tile, k-tile of 64 bf16, v_mfma_f32_32x32x16_bf16 ------------------------------------
 // A rows are bf16 already (trunk output) or f32 converted on the way to LDS; W comes pre-converted.  LDS rows are
 // 128 B + 16 B pad (9 slots: conflict-free ds_read_b128).
@@ -247,6 +344,20 @@ int launch_gemm(const GemmArgs& g_in, hipStream_t s) {
   SK_CHECK(g.a_mode != A_PLAIN || (g.lda % 4 == 0 && g.kc % 4 == 0), SK_EARG, "gemm: lda/kc alignment");
   if (g.W_bf16 && g.a_mode == A_PLAIN && g.kc == 0 && g.K % 8 == 0 && g.lda % 8 == 0 && g.ldw % 8 == 0 && g.ksplit == 1) {
     hipLaunchKernelGGL(gemm_bf16_kernel, dim3(cdiv(g.M, BM), cdiv(g.N, BN)), dim3(256), 0, s, g);
+    SK_HIP(hipGetLastError());
+    return SK_OK;
+  }
+  if (g.ksplit == 1 && g.M >= 2048 && g.N >= 128 && (g.kslices == 1 || g.a_mode == A_PLAIN) && !getenv("SIDEKIT_AMD_GEMM64")) {   // large problem: 128 x 128 tiles (same numbers)
+    dim3 grid2(cdiv(g.M, BM2), cdiv(g.N, BN2));
+    switch (g.a_mode) {
+      case A_PLAIN:
+        if (g.kslices > 1) hipLaunchKernelGGL((gemm128_kernel<LoadPlain, true>), grid2, dim3(256), 0, s, g);
+        else hipLaunchKernelGGL((gemm128_kernel<LoadPlain, false>), grid2, dim3(256), 0, s, g);
+        break;
+      case A_FRAMES: hipLaunchKernelGGL((gemm128_kernel<LoadFrames, false>), grid2, dim3(256), 0, s, g); break;
+      case A_POWER: hipLaunchKernelGGL((gemm128_kernel<LoadPower, false>), grid2, dim3(256), 0, s, g); break;
+      default: set_error("gemm: bad a_mode %d", g.a_mode); return SK_EARG;
+    }
     SK_HIP(hipGetLastError());
     return SK_OK;
   }

@@ -101,3 +101,17 @@ def test_mfcc_fft_matches_the_dft_contraction(gpu, fx, monkeypatch):
     for i, n in enumerate(lens):
         t = 1 + n // 512
         assert rel(fa[i, :, :t], ofe.mfcc_frontend(wav[i:i + 1, :n])[0]) < TOL, (i, n)
+
+
+def test_large_gemm_tiling_is_bit_identical(gpu, fx, monkeypatch):
+    """128 x 128 tiles (problems of >= 2048 rows) against the 64 x 64 kernel (SIDEKIT_AMD_GEMM64=1): the same k-ordered FMA
+    chain per output element, so the TDNN forward of a 40-utterance ragged batch (7k rows) must not move by one bit."""
+    m = _model(gpu, fx, "aam")
+    lens = numpy.random.RandomState(5).randint(32000, 160001, (40,)).tolist()
+    g = torch.Generator(device="cuda").manual_seed(11)
+    wav = 0.1 * torch.randn(len(lens), max(lens), device="cuda", generator=g)
+    logits_a, emb_a = m(wav, is_eval=True, lengths=lens)
+    monkeypatch.setenv("SIDEKIT_AMD_GEMM64", "1")
+    logits_b, emb_b = m(wav, is_eval=True, lengths=lens)
+    monkeypatch.delenv("SIDEKIT_AMD_GEMM64")
+    assert torch.equal(emb_a, emb_b) and torch.equal(logits_a, logits_b)
