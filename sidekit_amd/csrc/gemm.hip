@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 // Each output element sees the same k-ordered FMA chain as in the 64 x 64 kernel: results are bit-identical.
 constexpr int BM2 = 128, BN2 = 128;
 
-template <class LA, bool SLICED>
+template <bool SLICED>
 __global__ __launch_bounds__(256, 2) void gemm128_kernel(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) float As[BM2 * LDT];
   __shared__ __attribute__((aligned(16))) float Ws[BN2 * LDT];
@@ -177,16 +177,27 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(GemmArgs g) {
   const int wm = wave >> 1, wn = wave & 1;
   const int m0 = blockIdx.x * BM2, n0 = blockIdx.y * BN2;
   const int srow = tid >> 3, sk4 = (tid & 7) * 4;
+  // operand addresses advance with the k-tile (plain f32 A rows only; a dilated-conv A walks (tap, channel) without a division:
+  // k = tap * kc + c, row = m + tap * dil)
+  const float* A = reinterpret_cast<const float*>(g.A);
+  int kcur = 0, ctap = 0, ccol = sk4;   // this thread's k of the current fetch, split as tap * kc + ccol
+  auto seek = [&](int k0) {
+    kcur = k0 + sk4;
+    if (g.kc) { ctap = kcur / g.kc; ccol = kcur - ctap * g.kc; } else { ctap = 0; ccol = kcur; }
+  };
   float4 ra[4], rw[4];
-  auto fetch = [&](int k0) {
+  auto fetch = [&]() {     // loads the k-tile at kcur, then steps to the next one
+    const bool kok = kcur < g.K;
+    const long tapoff = (long)ctap * g.dil;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const int row = srow + q * 32;
-      ra[q] = LA::load(g, m0 + row, k0 + sk4);
-      const int n = n0 + row, k = k0 + sk4;
-      rw[q] = (n < g.N && k < g.K) ? *reinterpret_cast<const float4*>(g.W + (long)n * g.ldw + k)
-                                   : make_float4(0.f, 0.f, 0.f, 0.f);
+      const int row = srow + q * 32, m = m0 + row, n = n0 + row;
+      const long arow = m + tapoff;
+      ra[q] = (kok && m < g.M && arow < g.a_rows) ? *reinterpret_cast<const float4*>(A + arow * g.lda + ccol) : make_float4(0.f, 0.f, 0.f, 0.f);
+      rw[q] = (kok && n < g.N) ? *reinterpret_cast<const float4*>(g.W + (long)n * g.ldw + kcur) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    kcur += BK; ccol += BK;
+    if (g.kc) while (ccol >= g.kc) { ccol -= g.kc; ++ctap; }
   };
   f32x16 acc[2][2], tot[SLICED ? 2 : 1][SLICED ? 2 : 1];
   if constexpr (SLICED) {
@@ -207,7 +218,7 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(GemmArgs g) {
 #pragma unroll
         for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
     const int kt0 = z * per, kt1 = (kt0 + per < nk_all) ? kt0 + per : nk_all;
-    if (kt0 < kt1) fetch(kt0 * BK);
+    if (kt0 < kt1) { seek(kt0 * BK); fetch(); }
     for (int kt = kt0; kt < kt1; ++kt) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -215,7 +226,7 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(GemmArgs g) {
         *reinterpret_cast<float4*>(&Ws[(srow + q * 32) * LDT + sk4]) = rw[q];
       }
       __syncthreads();
-      if (kt + 1 < kt1) fetch((kt + 1) * BK);
+      if (kt + 1 < kt1 && !(g.dbg & 1)) fetch();
 #pragma unroll
       for (int kk = 0; kk < BK; kk += 8) {
         float4 a[2], b[2];
@@ -224,15 +235,23 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(GemmArgs g) {
           a[i] = *reinterpret_cast<const float4*>(&As[(wm * 64 + i * 32 + r) * LDT + kk + 4 * h]);
           b[i] = *reinterpret_cast<const float4*>(&Ws[(wn * 64 + i * 32 + r) * LDT + kk + 4 * h]);
         }
+        // the four accumulators take turns, so consecutive MFMAs are independent; each still sees k in order
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
-          }
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
       }
       __syncthreads();
     }
@@ -334,6 +353,7 @@ __global__ __launch_bounds__(256) void gemm_splitk_epilogue_kernel(GemmArgs g) {
 int launch_gemm(const GemmArgs& g_in, hipStream_t s) {
   GemmArgs g = g_in;
   g.ksplit = 1; g.kslices = 1;
+  { const char* e = getenv("SIDEKIT_AMD_GEMM_DBG"); g.dbg = e ? atoi(e) : 0; }
   if (g.splitk_ws && g.K >= 1024) {   // the summation order depends on K alone; M only decides where the slices run
     const int nk = (g.K + BK - 1) / BK;
     g.kslices = nk / 8 < 32 ? (nk / 8 > 1 ? nk / 8 : 1) : 32;   // >= 8 k-tiles per slice, at most 32 slices
@@ -347,17 +367,10 @@ int launch_gemm(const GemmArgs& g_in, hipStream_t s) {
     SK_HIP(hipGetLastError());
     return SK_OK;
   }
-  if (g.ksplit == 1 && g.M >= 2048 && g.N >= 128 && (g.kslices == 1 || g.a_mode == A_PLAIN) && !getenv("SIDEKIT_AMD_GEMM64")) {   // large problem: 128 x 128 tiles (same numbers)
+  if (g.ksplit == 1 && g.M >= 2048 && g.N >= 128 && g.a_mode == A_PLAIN && !g.a_bf16 && !getenv("SIDEKIT_AMD_GEMM64")) {   // large problem: 128 x 128 tiles (same numbers)
     dim3 grid2(cdiv(g.M, BM2), cdiv(g.N, BN2));
-    switch (g.a_mode) {
-      case A_PLAIN:
-        if (g.kslices > 1) hipLaunchKernelGGL((gemm128_kernel<LoadPlain, true>), grid2, dim3(256), 0, s, g);
-        else hipLaunchKernelGGL((gemm128_kernel<LoadPlain, false>), grid2, dim3(256), 0, s, g);
-        break;
-      case A_FRAMES: hipLaunchKernelGGL((gemm128_kernel<LoadFrames, false>), grid2, dim3(256), 0, s, g); break;
-      case A_POWER: hipLaunchKernelGGL((gemm128_kernel<LoadPower, false>), grid2, dim3(256), 0, s, g); break;
-      default: set_error("gemm: bad a_mode %d", g.a_mode); return SK_EARG;
-    }
+    if (g.kslices > 1) hipLaunchKernelGGL(gemm128_kernel<true>, grid2, dim3(256), 0, s, g);
+    else hipLaunchKernelGGL(gemm128_kernel<false>, grid2, dim3(256), 0, s, g);
     SK_HIP(hipGetLastError());
     return SK_OK;
   }

@@ -112,6 +112,7 @@ struct GemmArgs {
   float* splitk_ws;     // [ksplit][M][N] partial sums (M <= 512), or null: plain k order.  Non-null selects the sliced summation order for every M
   int ksplit;           // set by launch_gemm: slices run as blockIdx.z (1: inside the workgroup)
   int kslices;          // set by launch_gemm: slices the K range is summed in (a function of K alone)
+  int dbg;              // diagnostics only (SIDEKIT_AMD_GEMM_DBG, scripts/gemm_ablate.py): bit0 no operand prefetch after the first k-tile
 };
 GemmArgs gemm_args();   // zero-initialised, alpha = 1
 int launch_gemm(const GemmArgs& g, hipStream_t s);
