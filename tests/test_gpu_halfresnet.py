@@ -261,3 +261,31 @@ def test_embedding_does_not_depend_on_the_batch_size(gpu):
         big = m(wav, is_eval=True)[1]
         parts = torch.cat([m(wav[:7], is_eval=True)[1], m(wav[7:263], is_eval=True)[1], m(wav[263:], is_eval=True)[1]])
         assert torch.equal(big, parts), (dt, float((big - parts).abs().max()))
+
+
+def test_very_short_clips_as_the_first_call(gpu):
+    """A batch of 0.05-0.16 s clips (6-16 frames: ONE row tile per layer, T' = 1-2) as a fresh model's first call -- the
+    workspace is then sized by that shape alone (the SE-statistics buffers were once under-reserved for it) -- against each clip
+    run alone, bit for bit, in both precisions, and against the oracle in fp32.  Clips that pool over a single frame (T' = 1)
+    are NaN in the reference too: the global-context std is unbiased (pooling.py:155-158)."""
+    m = Xtractor(7205, model_archi="halfresnet34", loss="aam", seed=99).to(gpu).eval()
+    lens = [1290, 800, 1600, 1930, 2100, 2400, 2399, 815, 1500, 2559]
+    single_frame = [i for i, n in enumerate(lens) if 1 + n // 160 <= 8]           # 6-8 frames -> T' = 1
+    torch.manual_seed(21)
+    wav = 0.1 * torch.randn(len(lens), max(lens))
+    for dt in ("bf16", "fp32"):
+        m.compute_dtype = dt
+        _, emb = m(wav.cuda(), is_eval=True, lengths=lens)          # first call of this precision's handle
+        for i, n in enumerate(lens):
+            _, one = m(wav[i, :n].cuda(), is_eval=True)
+            if i in single_frame:
+                assert bool(torch.isnan(emb[i]).all()) and bool(torch.isnan(one[0]).all()), (dt, i, n)
+            else:
+                assert bool(torch.isfinite(emb[i]).all()) and torch.equal(one[0], emb[i]), (dt, i, n)
+    with torch.no_grad():
+        _, ref = oxv.forward_ragged([wav[i, :n] for i, n in enumerate(lens)], m.state_dict(), arch="halfresnet34")
+    for i, n in enumerate(lens):
+        if i in single_frame:
+            assert bool(torch.isnan(ref[i]).all()), (i, n)
+        else:
+            assert rel(emb[i], ref[i]) < TOL, (i, n)
