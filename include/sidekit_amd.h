@@ -168,6 +168,18 @@ int sk_pavx(const double* y, int64_t n, double* ghat_out, int64_t* width, double
 int sk_rocch_vertices(const double* pideal, int64_t n, int64_t n_tar, int64_t n_non, const int64_t* width, int64_t nbins,
                       double* pmiss, double* pfa);
 
+/* ---- wav staging for the streaming extractor (host code, no GPU needed) ---------------------------
+ * Replaces the per-file `torchaudio.load` of sidekit/bin/extract_xvectors.py:57-70 for canonical files: a pool of `threads`
+ * host threads (no interpreter lock) walks the RIFF headers / reads the samples.
+ * sk_wav_probe: kind[i] = 1 for RIFF/WAVE PCM 16-bit mono (nsamples / rate / data_offset filled), 0 for any other wav (the
+ *   caller decodes it), -1 if the file cannot be opened.
+ * sk_wav_read_pcm16: file i's samples -> dst[row[i] * ld .. + nsamples[i]) (dst: a pinned int16 staging buffer, ld in elements);
+ *   status[i] = 0 on success, -1 on a short read / open failure / nsamples[i] > ld. */
+int sk_wav_probe(const char* const* paths, int32_t n, int32_t threads, int32_t* nsamples, int32_t* rate, int64_t* data_offset,
+                 int32_t* kind);
+int sk_wav_read_pcm16(const char* const* paths, const int64_t* data_offset, const int32_t* nsamples, const int32_t* row, int32_t n,
+                      int32_t threads, int16_t* dst, int64_t ld, int32_t* status);
+
 #ifdef __cplusplus
 }
 #endif

@@ -54,6 +54,8 @@ SIGNATURES = {
     "sk_bench_conv": (ctypes.c_int, [_I32, _I32, _I32, _I32, _I32, _I32, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(_F64)]),
     "sk_pavx": (ctypes.c_int, [_P, _I64, _P, _P, _P, ctypes.POINTER(_I64)]),
     "sk_rocch_vertices": (ctypes.c_int, [_P, _I64, _I64, _I64, _P, _I64, _P, _P]),
+    "sk_wav_probe": (ctypes.c_int, [_P, _I32, _I32, _P, _P, _P, _P]),
+    "sk_wav_read_pcm16": (ctypes.c_int, [_P, _P, _P, _P, _I32, _I32, _P, _I64, _P]),
 }
 
 _lib = None

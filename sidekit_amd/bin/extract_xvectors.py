@@ -3,6 +3,7 @@
 Same arguments and files (``--model --wav-scp --out-scp [--out-spk-scp --spk2utt-file] --device
 --sample-rate``).  Differences, all on the caller's side of ``Xtractor.forward``: utterances are
 length-sorted into padded batches (``--batch-size``, each row is still processed as if run alone),
+decoding, host -> device copies and the forward overlap (``sidekit_amd/pipeline.py``),
 the bf16 trunk can be selected (``--dtype bf16``), ``--vad`` is refused (the reference fetches Silero
 VAD with ``torch.hub`` at run time, ``extract_xvectors.py:102`` -- no network here).  PCM wavs are
 decoded with ``scipy.io.wavfile`` (``soundfile`` is not installed); ``cmd |`` entries are run through
@@ -19,6 +20,7 @@ import torch
 
 from ..kaldi_io import ArkScpWriter, read_scp
 from ..nnet.xvector import Xtractor
+from ..pipeline import StreamingExtractor
 
 
 def read_wav_scp(wav_scp):
@@ -65,28 +67,14 @@ def load_model(model_path, device):
 
 
 @torch.no_grad()
-def main(xtractor, wav_scp, out_file, device, sample_rate=16000, out_file_spk="", spk2utt_file="", batch_size=64, dtype="fp32"):
+def main(xtractor, wav_scp, out_file, device, sample_rate=16000, out_file_spk="", spk2utt_file="", batch_size=64, dtype="fp32",
+         workers=8, window=8):
     utt2wav = read_wav_scp(wav_scp)
     xtractor.compute_dtype = dtype
-    waves = {}
-    for key, wav in utt2wav.items():
-        signal, sr = prepare(wav)
-        if sr != sample_rate:
-            raise ValueError(f"{key}: sample rate {sr} != {sample_rate} (resampling is out of scope; resample in the wav.scp pipe)")
-        waves[key] = signal
-    # length-sorted batches: bounded padding, every row still computed over its own length
-    order = sorted(waves, key=lambda k: waves[k].numel())
-    vecs = {}
-    for i in range(0, len(order), batch_size):
-        keys = order[i:i + batch_size]
-        lens = [waves[k].numel() for k in keys]
-        batch = torch.zeros(len(keys), max(lens))
-        for r, k in enumerate(keys):
-            batch[r, :lens[r]] = waves[k]
-        out = xtractor(batch.to(xtractor.device, non_blocking=True), is_eval=True, lengths=lens)
-        emb = (out[1] if isinstance(out, tuple) else out).cpu().numpy()
-        for r, k in enumerate(keys):
-            vecs[k] = emb[r:r + 1]          # (1, E) float matrix, what the reference writes (:147)
+    # decode threads -> length-sorted batches inside a sliding window -> pinned staging -> copy stream -> forward, all at
+    # once (sidekit_amd/pipeline.py); every row is still computed over its own length
+    stream = StreamingExtractor(xtractor, batch_size=batch_size, window=window, workers=workers, sample_rate=sample_rate)
+    vecs = dict(stream.run((key, ' '.join(wav)) for key, wav in utt2wav.items()))   # (1, E) float matrix per key, what the reference writes (:147)
     out_ark = os.path.realpath(os.path.join(os.path.dirname(out_file), os.path.splitext(os.path.basename(out_file))[0]))
     with ArkScpWriter(f"{out_ark}.ark", os.path.realpath(out_file)) as writer:
         for key in utt2wav:                  # wav.scp order, as the reference
@@ -118,6 +106,8 @@ def cli(argv=None):
     parser.add_argument("--device", default="cuda", type=str)
     parser.add_argument("--batch-size", type=int, default=64)
     parser.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"])
+    parser.add_argument("--workers", type=int, default=8, help="wav decoding threads")
+    parser.add_argument("--window", type=int, default=8, help="utterances are length-sorted inside windows of this many batches")
     args = parser.parse_args(argv)
     assert os.path.isfile(args.model), "NO SUCH FILE: %s" % args.model
     assert os.path.isfile(args.wav_scp), "NO SUCH FILE: %s" % args.wav_scp
@@ -128,7 +118,7 @@ def cli(argv=None):
         assert os.path.isdir(os.path.dirname(args.out_spk_scp)), "NO SUCH DIRECTORY: %s" % args.out_spk_scp
         assert os.path.isfile(args.spk2utt_file), "NO SUCH FILE: %s" % args.spk2utt_file
     xtractor, _ = load_model(args.model, args.device.strip().lower())
-    main(xtractor, args.wav_scp, args.out_scp, args.device, args.sample_rate, args.out_spk_scp, args.spk2utt_file, args.batch_size, args.dtype)
+    main(xtractor, args.wav_scp, args.out_scp, args.device, args.sample_rate, args.out_spk_scp, args.spk2utt_file, args.batch_size, args.dtype, args.workers, args.window)
 
 
 if __name__ == '__main__':

@@ -57,7 +57,8 @@ struct DevBuf {
   size_t bytes = 0;
   int ensure(size_t n) {
     if (n <= bytes) return SK_OK;
-    if (p) SK_HIP(hipFree(p));
+    // forwards are asynchronous: a batch queued earlier may still be reading this buffer when a longer batch makes it grow
+    if (p) { SK_HIP(hipDeviceSynchronize()); SK_HIP(hipFree(p)); }
     p = nullptr; bytes = 0;
     SK_HIP(hipMalloc(&p, n));
     bytes = n;
