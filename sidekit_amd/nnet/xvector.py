@@ -400,24 +400,35 @@ def extract_embeddings(idmap_name, model_filename, data_root_name, device, batch
                     starts.extend(w0.tolist())
                     stops.extend((w0 + win_len).tolist())
             else:
-                items = [_load_segment(data_root_name, idmap.rightids[i], file_extension, idmap.start[i], idmap.stop[i], sample_rate,
-                                       win_duration) for i in range(idmap.leftids.shape[0])]
-                order = sorted(range(len(items)), key=lambda i: items[i][0].numel())
-                vec = [None] * len(items)
-                for j in range(0, len(order), max(1, batch_size)):
-                    idx = order[j:j + max(1, batch_size)]
-                    lens = [items[i][0].numel() for i in idx]
-                    batch = torch.zeros(len(idx), max(lens))
-                    for r, i in enumerate(idx):
-                        batch[r, :lens[r]] = items[i][0]
-                    out = run(batch, lens)
-                    for r, i in enumerate(idx):
-                        vec[i] = out[r:r + 1]
+                # whole-file rows that are canonical PCM16 go file -> pinned staging natively; everything else (start / stop
+                # windows, other sample formats) is decoded by _load_segment on the pool; batches of `batch_size` length-sorted
+                # utterances stream through copy + forward while the next ones are staged (sidekit_amd/pipeline.py)
+                from ..pipeline import StreamingExtractor, probe_wavs
+                n = idmap.leftids.shape[0]
+                workers = max(4, int(num_thread))
+                path = [f"{data_root_name}/{idmap.rightids[i]}.{file_extension}" for i in range(n)]
+                whole = [i for i in range(n) if idmap.start[i] is None and idmap.stop[i] is None]
+                kind, ns, _, _ = probe_wavs([path[i] for i in whole], workers)
+                span = {i: (0, int(ns[j])) for j, i in enumerate(whole) if kind[j] == 1}
+
+                def deferred(i):
+                    def load():
+                        speech, a, b = _load_segment(data_root_name, idmap.rightids[i], file_extension, idmap.start[i], idmap.stop[i],
+                                                     sample_rate, win_duration)
+                        span[i] = (a, b)
+                        return speech
+                    return load
+
+                stream = StreamingExtractor(model, batch_size=max(1, batch_size), workers=workers, sample_rate=sample_rate,
+                                            norm_embedding=norm_embeddings)
+                vec = [None] * n
+                for i, v in stream.run((i, path[i] if i in span else deferred(i)) for i in range(n)):
+                    vec[i] = torch.from_numpy(v)
                 embed = vec
                 modelset = list(idmap.leftids)
                 segset = list(idmap.rightids)
-                starts = [it[1] for it in items]
-                stops = [it[1] + it[0].numel() for it in items]
+                starts = [span[i][0] for i in range(n)]
+                stops = [span[i][1] for i in range(n)]
     finally:
         model.compute_dtype = prev_dtype
     embeddings = StatServer()

@@ -187,7 +187,7 @@ class _Item:
 
 class StreamingExtractor:
     """``for key, vec in StreamingExtractor(model).run(entries)``: ``entries`` yields ``(key, source)`` with ``source`` a path /
-    ``cmd |`` string or an already decoded 1-D array; ``vec`` is the ``(1, E)`` float32 embedding.  Results arrive batch by
+    ``cmd |`` string, an already decoded 1-D array or a callable returning one; ``vec`` is the ``(1, E)`` float32 embedding.  Results arrive batch by
     batch (length-sorted inside a window of ``window * batch_size`` utterances), not in input order."""
 
     def __init__(self, model, batch_size=256, window=8, workers=8, pending=2, sample_rate=16000, norm_embedding=True, stage_ahead=2):
@@ -212,6 +212,8 @@ class StreamingExtractor:
             if rate != self.sample_rate:
                 raise ValueError(f"{key}: sample rate {rate} != {self.sample_rate} (resampling is out of scope; resample in the wav.scp pipe)")
         else:
+            if callable(source):                       # a deferred decode (e.g. an IdMap row with start / stop), run on the pool
+                source = source()
             sample = source.detach().cpu().numpy() if torch.is_tensor(source) else numpy.asarray(source)
         if sample.dtype != numpy.int16:
             sample = numpy.ascontiguousarray(sample, dtype=numpy.float32)
