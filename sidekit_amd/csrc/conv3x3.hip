@@ -354,6 +354,7 @@ void conv3x3_kernel(ConvArgs a) {
     stamp(1);
     __syncthreads();
     stamp(2);
+    __builtin_amdgcn_s_setprio(0);
     // k-step order inside a chunk: (tap, ks) for the padded image; the swizzled image walks (dw, ks, dh) so that one
     // swizzled address serves three consecutive steps (the row offset is an instruction immediate) and then dies
     auto step_tap = [](int kk) { return (C::SWZ && C::TAPS == 9 && !C::BLK) ? (kk % 3) * 3 + kk / (3 * C::KS) : kk / C::KS; };
@@ -484,6 +485,7 @@ void conv3x3_kernel(ConvArgs a) {
   constexpr int NC = C::WN * 32;                // channels of one out sub-tile
   constexpr int OPS = NC * C::EB + 16;          // out-tile position stride in LDS (padded against bank conflicts)
   static_assert(C::MT * OPS <= C::LDS, "out tile must fit the consumed input buffer");
+  __builtin_amdgcn_s_setprio(3);   // memory phases (epilogue, stores, next tile's DMA) ahead of other workgroups' MFMAs
   const int mvalid = (hout_b - ho0) * C::WOUT < C::MT ? (hout_b - ho0) * C::WOUT : C::MT;
   const size_t gpos0 = ((size_t)b * a.Hout + ho0) * C::WOUT;
   auto lds_elem = [&](int m, int c) {
