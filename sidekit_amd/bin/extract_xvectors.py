@@ -3,7 +3,9 @@
 Same arguments and files (``--model --wav-scp --out-scp [--out-spk-scp --spk2utt-file] --device
 --sample-rate``).  Differences, all on the caller's side of ``Xtractor.forward``: utterances are
 length-sorted into padded batches (``--batch-size``, each row is still processed as if run alone),
-decoding, host -> device copies and the forward overlap (``sidekit_amd/pipeline.py``),
+decoding, host -> device copies and the forward overlap (``sidekit_amd/pipeline.py``); under
+``python -m torch.distributed.run --nproc-per-node N -m sidekit_amd.bin.extract_xvectors ...`` the wav.scp is sharded over N GPUs
+(one all-gather of the x-vectors, rank 0 writes),
 the bf16 trunk can be selected (``--dtype bf16``), ``--vad`` is refused (the reference fetches Silero
 VAD with ``torch.hub`` at run time, ``extract_xvectors.py:102`` -- no network here).  PCM wavs are
 decoded with ``scipy.io.wavfile`` (``soundfile`` is not installed); ``cmd |`` entries are run through
@@ -17,10 +19,12 @@ import subprocess
 import numpy
 import scipy.io.wavfile
 import torch
+import torch.distributed as dist
 
 from ..kaldi_io import ArkScpWriter, read_scp
 from ..nnet.xvector import Xtractor
 from ..pipeline import StreamingExtractor
+from ..sharding import gather_xvectors, shard_range
 
 
 def read_wav_scp(wav_scp):
@@ -69,12 +73,28 @@ def load_model(model_path, device):
 @torch.no_grad()
 def main(xtractor, wav_scp, out_file, device, sample_rate=16000, out_file_spk="", spk2utt_file="", batch_size=64, dtype="fp32",
          workers=8, window=8):
+    """One process: the whole wav.scp.  Under ``torch.distributed.run`` (one process per GPU, an initialised process group):
+    every rank streams the contiguous shard ``shard_range(len(wav.scp), rank, world)``, the ``(N_r, E)`` blocks are gathered once
+    (``gather_xvectors``: RCCL all-gather, ragged counts) and rank 0 writes the ark / scp files in wav.scp order."""
     utt2wav = read_wav_scp(wav_scp)
     xtractor.compute_dtype = dtype
+    keys = list(utt2wav)
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    lo, hi = shard_range(len(keys), rank, world)
     # decode threads -> length-sorted batches inside a sliding window -> pinned staging -> copy stream -> forward, all at
     # once (sidekit_amd/pipeline.py); every row is still computed over its own length (SURVEY N2)
     stream = StreamingExtractor(xtractor, batch_size=batch_size, window=window, workers=workers, sample_rate=sample_rate)
-    vecs = dict(stream.run((key, ' '.join(wav)) for key, wav in utt2wav.items()))   # (1, E) float matrix per key, what the reference writes (:147)
+    mine = dict(stream.run((key, ' '.join(utt2wav[key])) for key in keys[lo:hi]))
+    if world > 1:
+        dev = torch.device(xtractor.device)
+        block = numpy.concatenate([mine[k] for k in keys[lo:hi]]) if hi > lo else numpy.zeros((0, xtractor.embedding_size), dtype=numpy.float32)
+        full = gather_xvectors(torch.from_numpy(numpy.ascontiguousarray(block, dtype=numpy.float32)).to(dev)).cpu().numpy()
+        if rank != 0:
+            return
+        vecs = {k: full[i:i + 1] for i, k in enumerate(keys)}      # contiguous shards in rank order = wav.scp order
+    else:
+        vecs = mine                                                 # (1, E) float matrix per key, what the reference writes (:147)
     out_ark = os.path.realpath(os.path.join(os.path.dirname(out_file), os.path.splitext(os.path.basename(out_file))[0]))
     with ArkScpWriter(f"{out_ark}.ark", os.path.realpath(out_file)) as writer:
         for key in utt2wav:                  # wav.scp order, as the reference
@@ -117,8 +137,20 @@ def cli(argv=None):
     if args.out_spk_scp:
         assert os.path.isdir(os.path.dirname(args.out_spk_scp)), "NO SUCH DIRECTORY: %s" % args.out_spk_scp
         assert os.path.isfile(args.spk2utt_file), "NO SUCH FILE: %s" % args.spk2utt_file
-    xtractor, _ = load_model(args.model, args.device.strip().lower())
+    device = args.device.strip().lower()
+    if "RANK" in os.environ and int(os.environ.get("WORLD_SIZE", "1")) > 1:   # python -m torch.distributed.run --nproc-per-node N -m sidekit_amd.bin.extract_xvectors ...
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        if device.startswith("cuda"):
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            torch.cuda.set_device(local)
+            device = f"cuda:{local}"
+            dist.init_process_group("nccl", device_id=torch.device(device))
+        else:
+            dist.init_process_group("gloo")
+    xtractor, _ = load_model(args.model, device)
     main(xtractor, args.wav_scp, args.out_scp, args.device, args.sample_rate, args.out_spk_scp, args.spk2utt_file, args.batch_size, args.dtype, args.workers, args.window)
+    if dist.is_initialized():
+        dist.destroy_process_group()
 
 
 if __name__ == '__main__':

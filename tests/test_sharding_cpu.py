@@ -64,3 +64,44 @@ def test_shard_ranges_partition():
     assert sorted(numpy.concatenate(parts).tolist()) == list(range(512))
     loads = [lens[p].sum() for p in parts]
     assert (max(loads) - min(loads)) / numpy.mean(loads) < 0.02
+
+
+class _StubXtractor:
+    """Stands in for the GPU model in the 2-rank CLI test: embedding = (sum, length, first, last sample)."""
+    device = "cpu"
+    embedding_size = 4
+    compute_dtype = "fp32"
+
+    def __call__(self, x, is_eval=False, norm_embedding=True, lengths=None):
+        rows = [torch.stack([x[r, :n].sum(), torch.tensor(float(n)), x[r, 0], x[r, n - 1]]) for r, n in enumerate(lengths)]
+        return None, torch.stack(rows).float()
+
+
+def _cli_worker(rank, world, port, wav_scp, out_scp):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from sidekit_amd.bin import extract_xvectors
+    extract_xvectors.main(_StubXtractor(), wav_scp, out_scp, "cpu", batch_size=3, workers=2, window=2)
+    dist.destroy_process_group()
+
+
+def test_extract_xvectors_cli_shards_the_wav_scp(tmp_path):
+    """`extract_xvectors.main` under an initialised 2-rank group: contiguous wav.scp shards (7 = 4 + 3 utterances), one ragged
+    gather, rank 0 alone writes the ark / scp in wav.scp order."""
+    import scipy.io.wavfile
+    from sidekit_amd.kaldi_io import read_scp
+    rs = numpy.random.RandomState(0)
+    expect = {}
+    with open(tmp_path / "wav.scp", "w") as f:
+        for i in range(7):
+            x = rs.randint(-20000, 20000, rs.randint(700, 3000)).astype(numpy.int16)
+            scipy.io.wavfile.write(tmp_path / f"u{i}.wav", 16000, x)
+            f.write(f"utt{i} {tmp_path / f'u{i}.wav'}\n")
+            v = x.astype(numpy.float32) / 32768.0
+            expect[f"utt{i}"] = numpy.array([v.astype(numpy.float64).sum(), len(v), v[0], v[-1]])
+    port = _free_port()
+    mp.spawn(_cli_worker, args=(2, port, str(tmp_path / "wav.scp"), str(tmp_path / "xv.scp")), nprocs=2, join=True)
+    got = dict(read_scp(str(tmp_path / "xv.scp")))
+    assert list(got) == [f"utt{i}" for i in range(7)]
+    for k, v in expect.items():
+        assert got[k].shape == (1, 4) and numpy.allclose(got[k][0], v, rtol=1e-5, atol=1e-3), k
