@@ -93,10 +93,20 @@ def load_entry(source):
     return parse_wav(data, source)
 
 
-def plan_batches(lengths, batch_size):
-    """Indices of ``lengths`` sorted by length, cut into batches of at most ``batch_size``: bounded padding per batch."""
+def plan_batches(lengths, batch_size, max_samples=None):
+    """Indices of ``lengths`` sorted by length, cut into batches of at most ``batch_size`` utterances and (``max_samples``) at
+    most that many PADDED samples (rows x longest row): bounded padding, and a window of hour-long files does not ask for a
+    ``batch_size`` x hour staging buffer and activation workspace."""
     order = sorted(range(len(lengths)), key=lambda i: lengths[i])
-    return [order[i:i + batch_size] for i in range(0, len(order), max(1, batch_size))]
+    batches, cur = [], []
+    for i in order:
+        if cur and (len(cur) >= max(1, batch_size) or (max_samples and (len(cur) + 1) * lengths[i] > max_samples)):
+            batches.append(cur)
+            cur = []
+        cur.append(i)
+    if cur:
+        batches.append(cur)
+    return batches
 
 
 class _Staging:
@@ -190,13 +200,15 @@ class StreamingExtractor:
     ``cmd |`` string, an already decoded 1-D array or a callable returning one; ``vec`` is the ``(1, E)`` float32 embedding.  Results arrive batch by
     batch (length-sorted inside a window of ``window * batch_size`` utterances), not in input order."""
 
-    def __init__(self, model, batch_size=256, window=8, workers=8, pending=2, sample_rate=16000, norm_embedding=True, stage_ahead=2):
+    def __init__(self, model, batch_size=256, window=8, workers=8, pending=2, sample_rate=16000, norm_embedding=True, stage_ahead=2,
+                 max_samples_per_batch=1 << 26):
         self.model = model
         self.batch_size = max(1, int(batch_size))
         self.window = max(1, int(window))
         self.workers = max(1, int(workers))
         self.pending = max(1, int(pending))
         self.stage_ahead = max(1, int(stage_ahead))
+        self.max_samples_per_batch = max_samples_per_batch   # 2^26 padded samples = 1024 x 4 s: caps staging and activation memory
         self.sample_rate = sample_rate
         self.norm_embedding = norm_embedding
         self.device = torch.device(model.device)
@@ -316,7 +328,7 @@ class StreamingExtractor:
                 if not chunk:
                     break
                 items = self._window_items(chunk, pool)
-                for idx in plan_batches([it.length for it in items], self.batch_size):
+                for idx in plan_batches([it.length for it in items], self.batch_size, self.max_samples_per_batch):
                     batch = [items[i] for i in idx]
                     while not free:                             # every slot is staged, in flight or waiting to be read back
                         if launched:

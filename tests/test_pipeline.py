@@ -59,6 +59,8 @@ def test_plan_batches():
     assert pipeline.plan_batches([5, 1, 3, 2, 9], 2) == [[1, 3], [2, 0], [4]]
     assert pipeline.plan_batches([], 4) == []
     assert pipeline.plan_batches([7, 7, 7], 8) == [[0, 1, 2]]
+    # padded-sample budget: rows x longest row <= 20; a single over-long utterance still gets its own batch
+    assert pipeline.plan_batches([4, 5, 6, 9, 30], 8, max_samples=20) == [[0, 1, 2], [3], [4]]
 
 
 class _StubModel:
