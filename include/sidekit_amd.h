@@ -173,12 +173,12 @@ int sk_rocch_vertices(const double* pideal, int64_t n, int64_t n_tar, int64_t n_
  * host threads (no interpreter lock) walks the RIFF headers / reads the samples.
  * sk_wav_probe: kind[i] = 1 for RIFF/WAVE PCM 16-bit mono (nsamples / rate / data_offset filled), 0 for any other wav (the
  *   caller decodes it), -1 if the file cannot be opened.
- * sk_wav_read_pcm16: file i's samples -> dst[row[i] * ld .. + nsamples[i]) (dst: a pinned int16 staging buffer, ld in elements);
- *   status[i] = 0 on success, -1 on a short read / open failure / nsamples[i] > ld. */
+ * sk_wav_read_pcm16: file i's samples -> dst[row[i] * ld .. + nsamples[i]) (dst: a pinned int16 staging buffer of n_rows rows, ld in
+ *   elements); status[i] = 0 on success, -1 on a short read / open failure / nsamples[i] > ld / row[i] outside [0, n_rows). */
 int sk_wav_probe(const char* const* paths, int32_t n, int32_t threads, int32_t* nsamples, int32_t* rate, int64_t* data_offset,
                  int32_t* kind);
 int sk_wav_read_pcm16(const char* const* paths, const int64_t* data_offset, const int32_t* nsamples, const int32_t* row, int32_t n,
-                      int32_t threads, int16_t* dst, int64_t ld, int32_t* status);
+                      int32_t threads, int16_t* dst, int64_t ld, int32_t n_rows, int32_t* status);
 
 #ifdef __cplusplus
 }

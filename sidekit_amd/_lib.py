@@ -55,7 +55,7 @@ SIGNATURES = {
     "sk_pavx": (ctypes.c_int, [_P, _I64, _P, _P, _P, ctypes.POINTER(_I64)]),
     "sk_rocch_vertices": (ctypes.c_int, [_P, _I64, _I64, _I64, _P, _I64, _P, _P]),
     "sk_wav_probe": (ctypes.c_int, [_P, _I32, _I32, _P, _P, _P, _P]),
-    "sk_wav_read_pcm16": (ctypes.c_int, [_P, _P, _P, _P, _I32, _I32, _P, _I64, _P]),
+    "sk_wav_read_pcm16": (ctypes.c_int, [_P, _P, _P, _P, _I32, _I32, _P, _I64, _I32, _P]),
 }
 
 _lib = None

@@ -77,11 +77,11 @@ int sk_wav_probe(const char* const* paths, int32_t n, int32_t threads, int32_t* 
 }
 
 int sk_wav_read_pcm16(const char* const* paths, const int64_t* data_offset, const int32_t* nsamples, const int32_t* row, int32_t n,
-                      int32_t threads, int16_t* dst, int64_t ld, int32_t* status) {
-  if (!paths || !data_offset || !nsamples || !row || n < 0 || !dst || ld <= 0 || !status) return SK_EARG;
+                      int32_t threads, int16_t* dst, int64_t ld, int32_t n_rows, int32_t* status) {
+  if (!paths || !data_offset || !nsamples || !row || n < 0 || !dst || ld <= 0 || n_rows <= 0 || !status) return SK_EARG;
   parallel_for(n, threads, [&](int32_t i) {
     status[i] = -1;
-    if (nsamples[i] < 0 || nsamples[i] > ld) return;
+    if (nsamples[i] < 0 || nsamples[i] > ld || row[i] < 0 || row[i] >= n_rows) return;
     const int fd = open(paths[i], O_RDONLY);
     if (fd < 0) return;
     unsigned char* out = reinterpret_cast<unsigned char*>(dst + (int64_t)row[i] * ld);

@@ -177,10 +177,10 @@ def read_pcm16(paths, offsets, nsamples, rows, dst, threads=8):
     rw = numpy.ascontiguousarray(rows, dtype=numpy.int32)
     status = numpy.zeros(n, dtype=numpy.int32)
     _lib.check(_lib.lib().sk_wav_read_pcm16(arr, off.ctypes.data, ns.ctypes.data, rw.ctypes.data, n, threads, dst.ctypes.data,
-                                            dst.strides[0] // 2, status.ctypes.data))
+                                            dst.strides[0] // 2, dst.shape[0], status.ctypes.data))
     bad = numpy.nonzero(status)[0]
     if bad.size:
-        raise IOError(f"Error processing wav file: {paths[int(bad[0])]} (short read)")
+        raise IOError(f"Error processing wav file: {paths[int(bad[0])]} (short read, or row / length outside the staging buffer)")
 
 
 class _Item:

@@ -137,3 +137,5 @@ def test_native_probe_and_read(tmp_path):
     assert (dst[1] == 7).all() and (dst[3] == 7).all() and (dst[2, 3001:] == 7).all() and (dst[0, 517:] == 7).all()
     with pytest.raises(IOError, match="short read"):
         pipeline.read_pcm16([str(tmp_path / "b.wav")], off[1:2], [5000], [0], numpy.zeros((1, 6000), dtype=numpy.int16))
+    with pytest.raises(IOError, match="outside the staging buffer"):       # a row index past the buffer is refused, not written
+        pipeline.read_pcm16([str(tmp_path / "b.wav")], off[1:2], ns[1:2], [4], dst)
