@@ -246,6 +246,7 @@ def main():
     ap.add_argument("--seconds", type=float, default=4.0)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--arch", default="halfresnet34", choices=["halfresnet34", "xvector"])
+    ap.add_argument("--ragged", action="store_true", help="variable-length 2-10 s utterances (BASELINE configs[3] with --arch xvector --dtype fp32 --batch 512)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--dry-run", action="store_true", help="CPU/gloo stand-in of the loop (plumbing test, not a measurement)")
@@ -280,6 +281,11 @@ def main():
     B, L = args.batch, int(args.seconds * 16000)
     g = torch.Generator(device=dev).manual_seed(rank)
     # the steps cycle through several resident batches so that no step finds its waveform in the Infinity Cache
+    lens = None
+    if args.ragged:   # BASELINE configs[3]: variable-length 2-10 s (RandomState(0), the lengths tests/test_gpu_fullsize.py uses)
+        import numpy
+        lens = numpy.random.RandomState(rank).randint(32000, 160001, (B,)).tolist()
+        L = max(lens)
     wavs = [0.1 * torch.randn(B, L, device=dev, generator=g) for _ in range(max(1, args.inputs))]
     # the step's x-vectors are gathered over RCCL WITHOUT stalling the next step: the collective runs on RCCL's stream
     # (async_op), two destination buffers alternate, and a step only waits for the gather issued two steps earlier; the timed
@@ -292,7 +298,7 @@ def main():
         wav = wavs[counter[0] % len(wavs)]
         k = counter[0]
         counter[0] += 1
-        _, emb = model(wav, is_eval=True)
+        _, emb = model(wav, is_eval=True, lengths=lens)
         if use_dist:
             while len(in_flight) >= 2:
                 in_flight.pop(0)[0].wait()
@@ -353,7 +359,8 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
             "config": {"workload": f"{'HalfResNet34' if args.arch == 'halfresnet34' else 'TDNN x-vector'} Xtractor.forward(is_eval=True), "
-                                   f"{dtype} trunk, batch={B} per GPU, synthetic {args.seconds:g} s @ 16 kHz (BASELINE.json configs[1])",
+                                   f"{dtype} trunk, batch={B} per GPU, synthetic " + (f"2-10 s (mean {sum(lens) / len(lens) / 16000:.2f} s, padded to {L / 16000:.2f} s)" if lens else f"{args.seconds:g} s")
+                                   + f" @ 16 kHz (BASELINE.json configs[{3 if args.arch != 'halfresnet34' else 1}])",
                        "batch_per_gpu": B, "samples_per_utt": L, "frames_per_utt": T, "resident_input_batches": len(wavs),
                        "parallelism": f"utterance-sharded x{world}" + (" + RCCL all-gather of x-vectors" if use_dist else "")},
         }
