@@ -84,63 +84,105 @@ __global__ __launch_bounds__(256) void dgemm_kernel(const double* __restrict__ A
 }
 
 // ---- all-pairs cosine scoring WITHOUT the score matrix (100k x 100k trials are 40 GB of float32) ---------------------
-// Persistent workgroups walk the 64 x 64 tiles of E . T^T (f32 MFMA, the arithmetic of sc_cosine), classify every score as
+// Persistent workgroups walk the 256 x 256 tiles of E . T^T (f32 MFMA, the arithmetic of sc_cosine), classify every score as
 // target / non-target from the two label vectors and count it into a private LDS histogram pair; the histograms are added to
 // the global 64-bit counters once, at the end.  EER / ROCCH then come from the counts (bosaris.detplot.eer_from_histograms).
 constexpr int HB = 8192;   // bins per histogram: 2 x 32 KB of LDS per workgroup, one persistent workgroup per CU
 
-__global__ __launch_bounds__(256, 1) void cosine_hist_kernel(const float* __restrict__ E, int Ne, const float* __restrict__ T, int Nt, int D,
-                                                             const int* __restrict__ le, const int* __restrict__ lt, int self_offset,
-                                                             float lo, float inv_width, unsigned long long* __restrict__ hist_tar,
-                                                             unsigned long long* __restrict__ hist_non) {
+// Tile: 256 x 256 per 1024-thread workgroup, sixteen waves of 64 x 64 (2 x 2 accumulator tiles each), k-tiles of 32 staged through
+// LDS with the next k-tile's operands prefetched into registers.  The 64 KB of histograms allow only ONE workgroup per CU, so the
+// latency hiding has to come from inside it: four waves per SIMD put 16 k matrix-pipe cycles between a prefetch and its use
+// (64 x 64 tiles with load-then-compute kept the pipes 26 % busy, 128 x 128 with four waves 33 %).
+constexpr int HT = 256, HLD = 36, HTHREADS = 1024;
+
+__global__ __launch_bounds__(HTHREADS) void cosine_hist_kernel(const float* __restrict__ E, int Ne, const float* __restrict__ T, int Nt, int D,
+                                                               const int* __restrict__ le, const int* __restrict__ lt, int self_offset,
+                                                               float lo, float inv_width, unsigned long long* __restrict__ hist_tar,
+                                                               unsigned long long* __restrict__ hist_non) {
   __shared__ unsigned hist[2 * HB];
-  __shared__ __attribute__((aligned(16))) float Es[64 * 36];
-  __shared__ __attribute__((aligned(16))) float Ts[64 * 36];
+  __shared__ __attribute__((aligned(16))) float Es[HT * HLD];
+  __shared__ __attribute__((aligned(16))) float Ts[HT * HLD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int r = lane & 31, h = lane >> 5, wm = wave >> 1, wn = wave & 1;
-  for (int i = tid; i < 2 * HB; i += 256) hist[i] = 0u;
-  const long tiles_n = (Nt + 63) / 64, ntiles = (long)((Ne + 63) / 64) * tiles_n;
-  const int srow = tid >> 3, sk4 = (tid & 7) * 4;
+  const int r = lane & 31, h = lane >> 5, wm = wave >> 2, wn = wave & 3;
+  for (int i = tid; i < 2 * HB; i += HTHREADS) hist[i] = 0u;
+  const long tiles_n = (Nt + HT - 1) / HT, ntiles = (long)((Ne + HT - 1) / HT) * tiles_n;
+  const int srow = tid >> 3, sk4 = (tid & 7) * 4;   // 128 rows x 8 chunks per pass, two passes per operand
+  const int nk = (D + 31) / 32;
   for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const int m0 = (int)(tile / tiles_n) * 64, n0 = (int)(tile % tiles_n) * 64;
-    f32x16 acc;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
-    for (int k0 = 0; k0 < D; k0 += 32) {
-      __syncthreads();
+    const int m0 = (int)(tile / tiles_n) * HT, n0 = (int)(tile % tiles_n) * HT;
+    float4 re[2], rt[2];
+    auto fetch = [&](int k0) {
+      const int k = k0 + sk4;
+      const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
-        const int row = srow + q * 32, k = k0 + sk4;
-        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-        *reinterpret_cast<float4*>(&Es[row * 36 + sk4]) = (m0 + row < Ne && k < D) ? *reinterpret_cast<const float4*>(E + (long)(m0 + row) * D + k) : z;
-        *reinterpret_cast<float4*>(&Ts[row * 36 + sk4]) = (n0 + row < Nt && k < D) ? *reinterpret_cast<const float4*>(T + (long)(n0 + row) * D + k) : z;
+        const int row = srow + q * 128;
+        re[q] = (m0 + row < Ne && k < D) ? *reinterpret_cast<const float4*>(E + (long)(m0 + row) * D + k) : z;
+        rt[q] = (n0 + row < Nt && k < D) ? *reinterpret_cast<const float4*>(T + (long)(n0 + row) * D + k) : z;
+      }
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+    fetch(0);
+    for (int kt = 0; kt < nk; ++kt) {
+      __syncthreads();            // every wave is done reading the previous k-tile
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        *reinterpret_cast<float4*>(&Es[(srow + q * 128) * HLD + sk4]) = re[q];
+        *reinterpret_cast<float4*>(&Ts[(srow + q * 128) * HLD + sk4]) = rt[q];
       }
       __syncthreads();
+      if (kt + 1 < nk) fetch((kt + 1) * 32);
 #pragma unroll
       for (int kk = 0; kk < 32; kk += 8) {
-        const float4 a = *reinterpret_cast<const float4*>(&Es[(wm * 32 + r) * 36 + kk + 4 * h]);
-        const float4 b = *reinterpret_cast<const float4*>(&Ts[(wn * 32 + r) * 36 + kk + 4 * h]);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+        float4 a[2], b[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          a[i] = *reinterpret_cast<const float4*>(&Es[(wm * 64 + i * 32 + r) * HLD + kk + 4 * h]);
+          b[i] = *reinterpret_cast<const float4*>(&Ts[(wn * 64 + i * 32 + r) * HLD + kk + 4 * h]);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
       }
     }
-    const int n = n0 + wn * 32 + r;
-    if (n < Nt) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = n0 + wn * 64 + j * 32 + r;
+      if (n >= Nt) continue;
       const int ln = lt[n];
 #pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const int m = m0 + wm * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
-        if (m >= Ne || (self_offset >= 0 && m + self_offset == n)) continue;
-        int bin = (int)floorf((acc[q] - lo) * inv_width);
-        bin = bin < 0 ? 0 : (bin >= HB ? HB - 1 : bin);
-        atomicAdd(&hist[(le[m] == ln ? 0 : HB) + bin], 1u);
-      }
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int m = m0 + wm * 64 + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+          if (m >= Ne || (self_offset >= 0 && m + self_offset == n)) continue;
+          int bin = (int)floorf((acc[i][j][q] - lo) * inv_width);
+          bin = bin < 0 ? 0 : (bin >= HB ? HB - 1 : bin);
+          atomicAdd(&hist[(le[m] == ln ? 0 : HB) + bin], 1u);
+        }
     }
   }
   __syncthreads();
-  for (int i = tid; i < 2 * HB; i += 256) {
+  for (int i = tid; i < 2 * HB; i += HTHREADS) {
     const unsigned c = hist[i];
     if (c) atomicAdd((i < HB ? hist_tar : hist_non) + (i & (HB - 1)), (unsigned long long)c);
   }
@@ -324,9 +366,9 @@ int sc_cosine_hist(const float* d_E, int32_t Ne, const float* d_T, int32_t Nt, i
   SK_HIP(hipMemsetAsync(d_hist_non, 0, (size_t)HB * 8, st));
   int dev = 0, cus = 256;
   if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-  const long ntiles = (long)cdiv(Ne, 64) * cdiv(Nt, 64);
-  const int grid = (int)(ntiles < (long)cus ? ntiles : (long)cus);   // persistent: one workgroup per CU (64 KB of histograms + the operand tiles)
-  hipLaunchKernelGGL(cosine_hist_kernel, dim3(grid), dim3(256), 0, st, d_E, Ne, d_T, Nt, D, d_labels_e, d_labels_t, self_offset, lo,
+  const long ntiles = (long)cdiv(Ne, HT) * cdiv(Nt, HT);
+  const int grid = (int)(ntiles < (long)cus ? ntiles : (long)cus);   // persistent: one workgroup per CU (64 KB of histograms + 74 KB of operand tiles)
+  hipLaunchKernelGGL(cosine_hist_kernel, dim3(grid), dim3(HTHREADS), 0, st, d_E, Ne, d_T, Nt, D, d_labels_e, d_labels_t, self_offset, lo,
                      (float)HB / (hi - lo), (unsigned long long*)d_hist_tar, (unsigned long long*)d_hist_non);
   SK_HIP(hipGetLastError());
   return SK_OK;
