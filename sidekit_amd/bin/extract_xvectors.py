@@ -148,7 +148,7 @@ def cli(argv=None):
         else:
             dist.init_process_group("gloo")
     xtractor, _ = load_model(args.model, device)
-    main(xtractor, args.wav_scp, args.out_scp, args.device, args.sample_rate, args.out_spk_scp, args.spk2utt_file, args.batch_size, args.dtype, args.workers, args.window)
+    main(xtractor, args.wav_scp, args.out_scp, device, args.sample_rate, args.out_spk_scp, args.spk2utt_file, args.batch_size, args.dtype, args.workers, args.window)
     if dist.is_initialized():
         dist.destroy_process_group()
 

@@ -13,10 +13,16 @@ target / non-target histograms, the per-rank counts summed with one all-reduce. 
 as a single rank.
 
 The corpus: speaker s is a fixed set of sinusoids (``RandomState(0)``), an utterance adds per-utterance phases, amplitude
-jitter and white noise (batch k of rank r is generated on the device with seed ``1000 + r * n_batches + k``) -- enough
-structure for the randomly initialised extractor to separate speakers with a non-trivial EER.  The PLDA parameters are a
-moment estimate (between / within speaker covariance of the training x-vectors); PLDA *training* proper
-(``sidekit/factor_analyser.py:830-932``) is out of scope, the parameters are inputs to the scoring path.
+jitter and white noise (a batch is generated on the device with seed ``1000 + index of its first utterance``) -- enough
+structure for the randomly initialised extractor to separate speakers with a non-trivial EER.  The PLDA parameters are inputs
+to the scoring path: ``--plda FILE`` reads ``(mu, F, Sigma)`` from a SIDEKIT PLDA HDF5 file (``sidekit_io.read_plda_hdf5``) or from
+an ``.npz`` with those three arrays (``tests/golden/config5.npz`` holds the ones the reference's ``FactorAnalyser.plda`` trained);
+without it a moment estimate (between / within speaker covariance of the training x-vectors) stands in, since PLDA *training*
+proper (``sidekit/factor_analyser.py:830-932``) is out of scope.
+
+``main(argv, model=None, scoring=None)``: the model and the module that scores (``cosine_matrix_device``, ``plda_matrix_device``,
+``cosine_histograms``) default to the GPU ones; ``--backend gloo --device cpu`` with injected stand-ins runs this driver's real
+control flow (ragged gather, row shards, ``self_offset``, the counter all-reduce) on CPU ranks (``tests/test_sharding_cpu.py``).
 """
 import argparse
 import json
@@ -68,7 +74,17 @@ def plda_moments(X, labels, rank):
     return mu, F, Sigma
 
 
-def main(argv=None):
+def load_plda(path):
+    """(mu, F, Sigma) float64 from a SIDEKIT PLDA HDF5 file (sidekit_io.py:282-324) or an .npz holding those three arrays."""
+    if path.endswith(".npz"):
+        z = numpy.load(path)
+        return tuple(numpy.asarray(z[k], dtype=numpy.float64) for k in ("mu", "F", "Sigma"))
+    from ..sidekit_io import read_plda_hdf5
+    mu, F, _G, Sigma = read_plda_hdf5(path)
+    return numpy.asarray(mu, dtype=numpy.float64), numpy.asarray(F, dtype=numpy.float64), numpy.asarray(Sigma, dtype=numpy.float64)
+
+
+def main(argv=None, model=None, scoring=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--utterances", type=int, default=4096)
     ap.add_argument("--batch", type=int, default=256)
@@ -79,64 +95,83 @@ def main(argv=None):
     ap.add_argument("--noise", type=float, default=0.004, help="white-noise level of the synthetic utterances (sets the EER: 0.004 -> cosine ~15 %, PLDA ~10 %; 0.03 -> 46 %)")
     ap.add_argument("--plda-rank", type=int, default=128)
     ap.add_argument("--all-pairs", action="store_true", help="also score every pair of the corpus into histograms (no N x N matrix)")
+    ap.add_argument("--plda", default=None, help="PLDA (mu, F, Sigma): SIDEKIT HDF5 or .npz; default: moment estimate from the corpus")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="nccl = RCCL over xGMI; gloo for CPU rehearsals")
+    ap.add_argument("--device", default="cuda", choices=["cuda", "cpu"], help="cpu only with an injected model / scoring module")
     args = ap.parse_args(argv)
+    scoring = iv_scoring if scoring is None else scoring
     assert args.utterances >= 2 * args.trials + 2 * args.speakers, "need utterances for enrolment, test and PLDA training"
     rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    if "RANK" in os.environ:
+    if args.device == "cuda":
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
+    else:
+        if model is None or scoring is iv_scoring:
+            raise RuntimeError("--device cpu needs an injected model and scoring module: the product path has no CPU fallback")
+        dev = torch.device("cpu")
+    sync = (lambda: torch.cuda.synchronize(dev)) if dev.type == "cuda" else (lambda: None)
+    own_group = "RANK" in os.environ and not dist.is_initialized()
+    if own_group:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
-    model = Xtractor(7205, model_archi="halfresnet34", loss="aam", seed=1234).to(dev).eval()
-    model.compute_dtype = args.dtype
+        dist.init_process_group(args.backend, **({"device_id": dev} if args.backend == "nccl" else {}))
+    if dist.is_initialized():
+        rank, world = dist.get_rank(), dist.get_world_size()
+    if model is None:
+        model = Xtractor(7205, model_archi="halfresnet34", loss="aam", seed=1234).to(dev).eval()
+        model.compute_dtype = args.dtype
     L = int(args.seconds * 16000)
     N = args.utterances
     labels = numpy.random.RandomState(1).randint(0, args.speakers, N).astype(numpy.int32)     # speaker of every utterance
     freqs, amps = speaker_table(args.speakers)
     start, stop = shard_range(N, rank, world)
     n_batches = (stop - start + args.batch - 1) // args.batch
-    torch.cuda.synchronize(dev)
+    sync()
     t0 = time.perf_counter()
     blocks = []
     for k in range(n_batches):
         lo = start + k * args.batch
         hi = min(lo + args.batch, stop)
-        g = torch.Generator(device=dev).manual_seed(1000 + rank * n_batches + k)
+        g = torch.Generator(device=dev).manual_seed(1000 + lo)        # a batch's seed = its first utterance: independent of the rank count when shards are batch aligned
         wav = synth_batch(labels[lo:hi], freqs, amps, L, args.noise, g, dev)
         blocks.append(model(wav, is_eval=True)[1])
-    local_xv = torch.cat(blocks) if blocks else torch.empty(0, 256, device=dev)
-    torch.cuda.synchronize(dev)
+    local_xv = torch.cat(blocks) if blocks else torch.empty(0, model.embedding_size, device=dev)
+    sync()
     t_extract = time.perf_counter() - t0
     t0 = time.perf_counter()
     xv = gather_xvectors(local_xv)                      # (utterances, 256) on every rank, still on the device
-    torch.cuda.synchronize(dev)
+    sync()
     t_gather = time.perf_counter() - t0
-    assert xv.shape == (N, 256) and xv.is_cuda
+    assert xv.shape == (N, model.embedding_size) and xv.device.type == dev.type
     # ---- the gathered x-vectors' own trial set: enrol [0, n), test [n, 2n), PLDA training on the rest
     n = args.trials
     E, T, train = xv[:n], xv[n:2 * n], xv[2 * n:]
     tar = labels[:n, None] == labels[None, n:2 * n]
     t0 = time.perf_counter()
-    cos_rows = score_sharded(lambda a, b: iv_scoring.cosine_matrix_device(E[a:b], T, dev), n)   # rank 0 gets (n, n), device resident
-    torch.cuda.synchronize(dev)
+    cos_rows = score_sharded(lambda a, b: scoring.cosine_matrix_device(E[a:b], T, dev), n)   # rank 0 gets (n, n), device resident
+    sync()
     t_cos = time.perf_counter() - t0
-    mu, F, Sigma = plda_moments(train.cpu().numpy(), labels[2 * n:], args.plda_rank)      # identical on every rank (same gathered data)
+    if args.plda:
+        mu, F, Sigma = load_plda(args.plda)
+        assert mu.shape[0] == xv.shape[1], "PLDA dimension differs from the x-vectors'"
+    else:
+        mu, F, Sigma = plda_moments(train.cpu().numpy(), labels[2 * n:], args.plda_rank)  # identical on every rank (same gathered data)
     Phi, Psi, cst = iv_scoring.plda_parameters(mu, F, Sigma)
     mu_d = torch.as_tensor(mu, device=dev)
     Ec, Tc = E.double() - mu_d, T.double() - mu_d                                        # center_stat1 (statserver.py:810-817)
     t0 = time.perf_counter()
-    plda_rows = score_sharded(lambda a, b: iv_scoring.plda_matrix_device(Ec[a:b], Tc, Phi, Psi, cst, 1.0, dev), n)
-    torch.cuda.synchronize(dev)
+    plda_rows = score_sharded(lambda a, b: scoring.plda_matrix_device(Ec[a:b], Tc, Phi, Psi, cst, 1.0, dev), n)
+    sync()
     t_plda = time.perf_counter() - t0
     out = {"ranks": world, "utterances": N, "x_vectors_per_s": N / t_extract, "extract_s": t_extract, "all_gather_s": t_gather,
-           "trials": n * n, "cosine_score_s": t_cos, "plda_score_s": t_plda, "dtype": args.dtype}
+           "trials": n * n, "cosine_score_s": t_cos, "plda_score_s": t_plda, "dtype": args.dtype,
+           "plda": args.plda or "moment estimate"}
     if args.all_pairs:
         # matrix-free: rank r counts the pairs (i, j), i in its enrolment-row shard, j over the whole corpus, i != j
         a, b = shard_range(N, rank, world)
         lab_d = torch.as_tensor(labels, device=dev)
         t0 = time.perf_counter()
-        ht, hn = iv_scoring.cosine_histograms(xv[a:b], xv, lab_d[a:b], lab_d, self_offset=a, device=dev)
-        torch.cuda.synchronize(dev)
+        ht, hn = scoring.cosine_histograms(xv[a:b], xv, lab_d[a:b], lab_d, self_offset=a, device=dev)
+        sync()
         counts = torch.as_tensor(numpy.stack([ht, hn]).astype(numpy.int64), device=dev)
         if dist.is_initialized():
             dist.all_reduce(counts)
@@ -148,8 +183,9 @@ def main(argv=None):
             s = rows.cpu().numpy().astype(float)
             out[f"{name}_eer"] = float(rocch2eer(*rocch(s[tar], s[~tar])))
         print(json.dumps(out), flush=True)
-    if dist.is_initialized():
+    if own_group:
         dist.destroy_process_group()
+    return out if rank == 0 else None
 
 
 if __name__ == "__main__":

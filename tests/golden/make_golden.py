@@ -13,7 +13,7 @@ The torchaudio stand-in's MelSpectrogram / MFCC compute with oracle/frontend.py 
 restatement of torchaudio 0.8.2), so every *network* fixture is cut at the features seam, where no
 stand-in arithmetic is involved; wav-level fixtures are labelled `unpinned_frontend`.
 
-Usage:  PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py [halfresnet34] [tdnn] [scoring] [asnorm] [examples]
+Usage:  PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py [halfresnet34] [tdnn] [scoring] [asnorm] [examples] [config5]
 """
 import importlib
 import os
@@ -376,10 +376,66 @@ def examples_fixtures(mods, out):
     print("examples_decode.npz", {k: getattr(v, "shape", v) for k, v in fx.items()})
 
 
+def config5_fixtures(mods, out):
+    """BASELINE config 5 at its stated size, pinned by the reference itself: PLDA ``(mu, F, Sigma)`` trained by the
+    reference's ``FactorAnalyser.plda`` (factor_analyser.py:830-932, rank 128, 10 EM iterations) on the disjoint synthetic training
+    set, then the reference's ``cosine_scoring`` / ``fast_PLDA_scoring`` (iv_scoring.py:63-113,370-477) on the 1000 x 1000 full trial
+    mask, ``Scores.get_tar_non`` and ``rocch`` / ``rocch2eer`` (detplot.py:354-436).  Stored: the PLDA parameters, digests of the
+    regenerated inputs, a strided sample + row / column sums + moments of both score matrices, the ROCCH vertices and the two EERs."""
+    from oracle import scoring as osc
+    sys.path.insert(0, HERE)
+    import config5_inputs as c5
+    ivs, sts_mod, bos = mods["sidekit.iv_scoring"], mods["sidekit.statserver"], mods["sidekit.bosaris"]
+    det = mods["sidekit.bosaris.detplot"]
+    fa = importlib.import_module("sidekit.factor_analyser")
+
+    def make_sts(models, segs, X):
+        s = sts_mod.StatServer()
+        s.modelset, s.segset = numpy.array(models, dtype="|O"), numpy.array(segs, dtype="|O")
+        s.start, s.stop = numpy.empty(len(segs), dtype="|O"), numpy.empty(len(segs), dtype="|O")
+        s.stat0 = numpy.ones((len(segs), 1))
+        s.stat1 = numpy.array(X, dtype=numpy.float64)
+        return s
+
+    X, lab = c5.plda_training_set()
+    train = make_sts([f"spk{l:04d}" for l in lab], c5.ids("tr", X.shape[0]), X)
+    plda = fa.FactorAnalyser()
+    plda.plda(train, rank_f=c5.PLDA_RANK, nb_iter=10, save_final=False)
+    mu, F, Sigma = plda.mean, plda.F, plda.Sigma
+    E, T, spk_e, spk_t = c5.trial_set()
+    enr_ids, tst_ids = c5.ids("enr", c5.NE), c5.ids("tst", c5.NT)
+    enroll, test = make_sts(enr_ids, enr_ids, E), make_sts(tst_ids, tst_ids, T)
+    mm, ss = numpy.meshgrid(numpy.arange(c5.NE), numpy.arange(c5.NT), indexing="ij")
+    models, segs = enr_ids[mm.ravel()], tst_ids[ss.ravel()]
+    tar_mask = spk_e[:, None] == spk_t[None, :]
+    ndx = bos.Ndx(models=models, testsegs=segs)
+    key = bos.Key(models=models, testsegs=segs, trials=numpy.where(tar_mask.ravel(), "target", "nontarget").astype("|O"))
+    assert ndx.trialmask.all() and numpy.array_equal(key.tar, tar_mask)
+    fx = {"mu": mu, "F": F, "Sigma": Sigma, "E_digest": c5.digest(E), "T_digest": c5.digest(T), "X_digest": c5.digest(X),
+          "n_target": int(tar_mask.sum()), "sample_rows": 7, "sample_cols": 11}
+    for tag, sc in (("cos", ivs.cosine_scoring(enroll, test, ndx, wccn=None, check_missing=True, device=torch.device("cpu"))),
+                    ("plda", ivs.fast_PLDA_scoring(enroll, test, ndx, mu, F, Sigma))):
+        assert list(sc.modelset) == list(enr_ids) and list(sc.segset) == list(tst_ids) and sc.scoremask.all()
+        m = sc.scoremat
+        tar, non = sc.get_tar_non(key)
+        pmiss, pfa = det.rocch(tar, non)
+        m64 = m.astype(numpy.float64)
+        fx.update({f"{tag}_dtype": str(m.dtype), f"{tag}_sample": m[::7, ::11].copy(), f"{tag}_row_sums": m64.sum(axis=1),
+                   f"{tag}_col_sums": m64.sum(axis=0), f"{tag}_moments": numpy.array([m64.mean(), m64.std(), m64.min(), m64.max()]),
+                   f"{tag}_pmiss": pmiss, f"{tag}_pfa": pfa, f"{tag}_eer": det.rocch2eer(pmiss, pfa)})
+        print(tag, m.dtype, "EER", fx[f"{tag}_eer"])
+        # the oracle must agree with the reference it restates, at this size too
+        o = osc.cosine_scores(E, T) if tag == "cos" else osc.fast_plda_scores(E, T, mu, F, Sigma)
+        assert numpy.allclose(o, m, rtol=1e-9, atol=2e-6 if tag == "cos" else 1e-9), numpy.abs(o - m).max()
+        assert abs(osc.eer(o[tar_mask], o[~tar_mask]) - fx[f"{tag}_eer"]) < 1e-9
+    numpy.savez_compressed(os.path.join(out, "config5.npz"), **fx)
+    print("config5.npz", {k: getattr(v, "shape", v) for k, v in fx.items()})
+
+
 def main():
     mods = import_reference()
     torch.set_num_threads(8)
-    only = sys.argv[1:] or ["halfresnet34", "tdnn", "scoring", "asnorm", "examples"]
+    only = sys.argv[1:] or ["halfresnet34", "tdnn", "scoring", "asnorm", "examples", "config5"]
     if "halfresnet34" in only:
         halfresnet_fixtures(mods, HERE)
     if "tdnn" in only:
@@ -390,6 +446,8 @@ def main():
         asnorm_fixtures(mods, HERE)
     if "examples" in only:
         examples_fixtures(mods, HERE)
+    if "config5" in only:
+        config5_fixtures(mods, HERE)
 
 
 if __name__ == "__main__":

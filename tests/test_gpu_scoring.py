@@ -104,6 +104,54 @@ def test_million_trial_matrix_and_eer(gpu):
     assert abs(osc.eer(got[tar_mask], got[~tar_mask]) - osc.eer(want[tar_mask], want[~tar_mask])) < 5e-4
 
 
+def test_config5_pinned_by_the_reference_at_full_size(gpu, golden_dir):
+    """BASELINE config 5 as stated: 1000 enrolment models x 1000 test segments, PLDA (mu, F, Sigma) trained by the
+    reference's FactorAnalyser.plda on the disjoint synthetic set; the fixture holds the REFERENCE's cosine_scoring /
+    fast_PLDA_scoring matrices (strided sample, row / column sums, moments), ROCCH vertices and EERs (make_golden.py config5).
+    The public API (StatServer + Ndx + Key in, Scores out) on the GPU must reproduce them: 1e-6 relative in f64 (measured 1e-12),
+    f32 cosine 2e-6 absolute, EER +-0.05 % absolute (measured: identical)."""
+    import sys
+    sys.path.insert(0, golden_dir)
+    import config5_inputs as c5
+    fx = numpy.load(os.path.join(golden_dir, "config5.npz"))
+    E, T, spk_e, spk_t = c5.trial_set()
+    numpy.testing.assert_array_equal(c5.digest(E), fx["E_digest"])
+    numpy.testing.assert_array_equal(c5.digest(T), fx["T_digest"])
+    enr_ids, tst_ids = c5.ids("enr", c5.NE), c5.ids("tst", c5.NT)
+    enroll, test = StatServer.from_arrays(enr_ids, enr_ids, E), StatServer.from_arrays(tst_ids, tst_ids, T)
+    mm, ss = numpy.meshgrid(numpy.arange(c5.NE), numpy.arange(c5.NT), indexing="ij")
+    models, segs = enr_ids[mm.ravel()], tst_ids[ss.ravel()]
+    tar_mask = spk_e[:, None] == spk_t[None, :]
+    ndx = Ndx(models=models, testsegs=segs)
+    key = Key(models=models, testsegs=segs, trials=numpy.where(tar_mask.ravel(), "target", "nontarget").astype(object))
+    assert ndx.trialmask.all() and numpy.array_equal(key.tar, tar_mask) and int(tar_mask.sum()) == int(fx["n_target"])
+    cos = iv_scoring.cosine_scoring(enroll, test, ndx)
+    plda = iv_scoring.fast_PLDA_scoring(enroll, test, ndx, fx["mu"], fx["F"], fx["Sigma"])
+    for tag, sc in (("cos", cos), ("plda", plda)):
+        m = sc.scoremat
+        assert str(m.dtype) == str(fx[f"{tag}_dtype"]) and m.shape == (c5.NE, c5.NT) and sc.scoremask.all()
+        assert list(sc.modelset) == list(enr_ids) and list(sc.segset) == list(tst_ids)
+        m64 = m.astype(numpy.float64)
+        if tag == "cos":
+            numpy.testing.assert_allclose(m[::7, ::11], fx["cos_sample"], rtol=0, atol=2e-6)
+            numpy.testing.assert_allclose(m64.sum(axis=1), fx["cos_row_sums"], rtol=0, atol=1e-4)
+            numpy.testing.assert_allclose(m64.sum(axis=0), fx["cos_col_sums"], rtol=0, atol=1e-4)
+        else:
+            scale = numpy.abs(fx["plda_sample"]).max()
+            assert numpy.abs(m[::7, ::11] - fx["plda_sample"]).max() / scale < 1e-9
+            numpy.testing.assert_allclose(m64.sum(axis=1), fx["plda_row_sums"], rtol=1e-9, atol=1e-6)
+            numpy.testing.assert_allclose(m64.sum(axis=0), fx["plda_col_sums"], rtol=1e-9, atol=1e-6)
+        numpy.testing.assert_allclose([m64.mean(), m64.std(), m64.min(), m64.max()], fx[f"{tag}_moments"], rtol=1e-6, atol=2e-6)
+        tar, non = sc.get_tar_non(key)
+        assert tar.shape[0] == int(fx["n_target"]) and non.shape[0] == c5.NE * c5.NT - int(fx["n_target"])
+        pmiss, pfa = rocch(tar.astype(float), non.astype(float))
+        assert abs(rocch2eer(pmiss, pfa) - float(fx[f"{tag}_eer"])) < 5e-4          # +-0.05 % absolute (north star)
+        if tag == "plda":                                                           # f64 end to end: the hull itself is the reference's
+            numpy.testing.assert_allclose(pmiss, fx["plda_pmiss"], atol=1e-12)
+            numpy.testing.assert_allclose(pfa, fx["plda_pfa"], atol=1e-12)
+            assert abs(rocch2eer(pmiss, pfa) - float(fx["plda_eer"])) < 1e-9
+
+
 def test_listed_trials_cosine(gpu):
     """compute_spk_cosine.py:18-26,50-55: speaker-mean enrolment, L2, cosine per listed trial (float64 maths)."""
     import ctypes

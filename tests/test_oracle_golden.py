@@ -165,3 +165,28 @@ def test_oracle_reproduces_examples_decode_embeddings(golden_dir):
             _, first = oxv.halfresnet34_forward(x[:64000].unsqueeze(0), sd)
         assert torch.allclose(full, torch.from_numpy(ex[f"emb_full_{k}_unpinned_frontend"]), atol=2e-6)
         assert torch.allclose(first, torch.from_numpy(ex[f"emb_first4s_{k}_unpinned_frontend"]), atol=2e-6)
+
+
+def test_config5_oracle_matches_reference_at_full_size(golden_dir):
+    """BASELINE config 5 as stated: 1000 x 1000 trials, PLDA trained by the reference's FactorAnalyser.plda; the oracle against the
+    reference's cosine / fast-PLDA matrices (strided sample, row / column sums, moments) and its two ROCCH EERs."""
+    import sys
+    sys.path.insert(0, golden_dir)
+    import config5_inputs as c5
+    fx = numpy.load(os.path.join(golden_dir, "config5.npz"))
+    E, T, spk_e, spk_t = c5.trial_set()
+    numpy.testing.assert_array_equal(c5.digest(E), fx["E_digest"])
+    numpy.testing.assert_array_equal(c5.digest(T), fx["T_digest"])
+    numpy.testing.assert_array_equal(c5.digest(c5.plda_training_set()[0]), fx["X_digest"])
+    tar = spk_e[:, None] == spk_t[None, :]
+    assert int(tar.sum()) == int(fx["n_target"])
+    for tag, m, tol in (("cos", osc.cosine_scores(E, T), dict(rtol=0, atol=2e-6)),
+                        ("plda", osc.fast_plda_scores(E, T, fx["mu"], fx["F"], fx["Sigma"]), dict(rtol=1e-9, atol=1e-9))):
+        numpy.testing.assert_allclose(m[::7, ::11], fx[f"{tag}_sample"], **tol)
+        numpy.testing.assert_allclose(m.sum(axis=1), fx[f"{tag}_row_sums"], rtol=1e-6 if tag == "cos" else 1e-9, atol=1e-4 if tag == "cos" else 1e-7)
+        numpy.testing.assert_allclose(m.sum(axis=0), fx[f"{tag}_col_sums"], rtol=1e-6 if tag == "cos" else 1e-9, atol=1e-4 if tag == "cos" else 1e-7)
+        pm, pf = osc.rocch(m[tar], m[~tar])
+        if tag == "plda":
+            numpy.testing.assert_allclose(pm, fx["plda_pmiss"], atol=1e-12)
+            numpy.testing.assert_allclose(pf, fx["plda_pfa"], atol=1e-12)
+        assert abs(osc.rocch2eer(pm, pf) - float(fx[f"{tag}_eer"])) < 1e-6

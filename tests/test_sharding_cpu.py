@@ -105,3 +105,86 @@ def test_extract_xvectors_cli_shards_the_wav_scp(tmp_path):
     assert list(got) == [f"utt{i}" for i in range(7)]
     for k, v in expect.items():
         assert got[k].shape == (1, 4) and numpy.allclose(got[k][0], v, rtol=1e-5, atol=1e-3), k
+
+
+# ---- the sharded extraction + scoring driver itself (bin/shard_extract_score.py) on 2 gloo ranks -------------------------------
+class _BandEnergyXtractor:
+    """CPU stand-in for the GPU model inside ``shard_extract_score.main``: 16 log band energies of the first 2048 samples,
+    L2-normalised -- enough for the synthetic sinusoid speakers to separate with a non-trivial EER."""
+    embedding_size = 16
+    compute_dtype = "fp32"
+
+    def __call__(self, x, is_eval=False):
+        p = torch.fft.rfft(x[:, :2048].double() * torch.hann_window(2048, dtype=torch.float64), dim=1).abs().pow(2)[:, :1024]
+        e = torch.log(p.reshape(x.shape[0], 16, 64).sum(dim=2) + 1e-9)
+        e = e - e.mean(dim=1, keepdim=True)
+        return None, torch.nn.functional.normalize(e, dim=1).float()
+
+
+class _CpuScoring:
+    """CPU stand-ins with the signatures and return types of ``iv_scoring.cosine_matrix_device / plda_matrix_device /
+    cosine_histograms`` (the GPU entry points the driver calls); row independent on purpose (one dot product per score), so that
+    a row shard of the matrix equals those rows of the whole matrix bit for bit."""
+
+    @staticmethod
+    def cosine_matrix_device(e, t, device=None):
+        return (e.double()[:, None, :] * t.double()[None, :, :]).sum(dim=2).float()
+
+    @staticmethod
+    def plda_matrix_device(e, t, Phi, Psi, cst, scaling_factor=1., device=None):
+        Phi, Psi = torch.as_tensor(Phi), torch.as_tensor(Psi)
+        qe, qt = 0.5 * ((e @ Phi) * e).sum(dim=1), 0.5 * ((t @ Phi) * t).sum(dim=1)
+        cross = ((e @ Psi)[:, None, :] * t[None, :, :]).sum(dim=2)
+        return scaling_factor * (qe[:, None] + qt[None, :] + cst + cross)
+
+    @staticmethod
+    def cosine_histograms(e, t, le, lt, self_offset=None, lo=-1.0, hi=1.0, device=None):
+        from sidekit_amd.iv_scoring import HIST_BINS
+        s = _CpuScoring.cosine_matrix_device(e, t).numpy()
+        keep = numpy.ones(s.shape, dtype=bool)
+        if self_offset is not None:
+            i = numpy.arange(s.shape[0])
+            keep[i, i + self_offset] = False
+        tar = (le.cpu().numpy()[:, None] == lt.cpu().numpy()[None, :])
+        b = numpy.clip(numpy.floor((s - lo) / (hi - lo) * HIST_BINS).astype(numpy.int64), 0, HIST_BINS - 1)
+        return (numpy.bincount(b[keep & tar], minlength=HIST_BINS).astype(numpy.uint64),
+                numpy.bincount(b[keep & ~tar], minlength=HIST_BINS).astype(numpy.uint64))
+
+
+_DRIVER_ARGS = ["--utterances", "192", "--batch", "16", "--seconds", "0.2", "--trials", "48", "--speakers", "12", "--plda-rank", "6",
+                "--noise", "0.1", "--all-pairs", "--backend", "gloo", "--device", "cpu"]
+
+
+def _driver_worker(rank, world, port, out_dir):
+    import json
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from sidekit_amd.bin import shard_extract_score
+    out = shard_extract_score.main(_DRIVER_ARGS, model=_BandEnergyXtractor(), scoring=_CpuScoring)   # opens the gloo group itself
+    assert (out is not None) == (rank == 0)
+    if rank == 0:
+        with open(os.path.join(out_dir, "two_ranks.json"), "w") as f:
+            json.dump(out, f)
+
+
+def test_shard_extract_score_driver_on_two_ranks(tmp_path, monkeypatch):
+    """The driver's real control flow on 2 gloo ranks against its own 1-rank run: contiguous shards (96 + 96 utterances, batch
+    aligned so both runs synthesise the same waveforms), ONE ragged gather, cosine + PLDA row shards gathered on rank 0,
+    ``cosine_histograms(self_offset=a)`` per rank + the counter all-reduce; every EER and the pair count equal the 1-rank run's."""
+    import json
+    from sidekit_amd.bin import shard_extract_score
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    one = shard_extract_score.main(_DRIVER_ARGS, model=_BandEnergyXtractor(), scoring=_CpuScoring)
+    assert one["ranks"] == 1 and one["all_pairs"] == 192 * 191 and 0.0 < one["cosine_eer"] < 0.5
+    port = _free_port()
+    mp.spawn(_driver_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    with open(tmp_path / "two_ranks.json") as f:
+        two = json.load(f)
+    assert two["ranks"] == 2 and two["utterances"] == 192 and two["trials"] == 48 * 48
+    assert two["all_pairs"] == one["all_pairs"]
+    for k in ("cosine_eer", "plda_eer", "all_pairs_eer"):
+        assert two[k] == one[k], (k, one[k], two[k])
+    # the injected-module switch is not a fallback: the product entry point refuses a CPU device
+    import pytest
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        shard_extract_score.main(["--device", "cpu", "--utterances", "192", "--trials", "48", "--speakers", "12"])
