@@ -75,6 +75,13 @@ int xt_reserve(xt_handle* h, int32_t max_batch, int64_t max_samples);
 int xt_forward(xt_handle* h, const float* d_wav, int64_t wav_ld, const int32_t* h_nsamples, int32_t B, int64_t L,
                float* d_emb, float* d_logits, void* stream);
 
+/* Same, for 16-bit PCM as the files hold it: the decode of the reference driver (sidekit/bin/extract_xvectors.py:57-70,
+ * soundfile.read -> float32 = int16 / 32768) happens inside the front-end kernel's load, so a wav file's payload goes
+ * disk -> pinned memory -> device -> STFT without a conversion pass on either side.  x-vectors are bit-identical to
+ * xt_forward on the widened samples.  d_pcm int16 [B][pcm_ld]. */
+int xt_forward_pcm16(xt_handle* h, const int16_t* d_pcm, int64_t pcm_ld, const int32_t* h_nsamples, int32_t B, int64_t L,
+                     float* d_emb, float* d_logits, void* stream);
+
 /* Same, entered after the front-end (everything after xvector.py:885): the features->embedding
  * seam the parity fixtures are cut at.  d_feats float32 (B, 80, T) as MelSpecFrontEnd / MfccFrontEnd
  * return it; h_frames NULL = all T. */

@@ -41,7 +41,7 @@ for N in (1000, 16384):
     od = torch.empty(N, N, device=dev, dtype=torch.float64)
     s = timed(lambda: _lib.check(lib.sc_plda_fast(ed.data_ptr(), N, td.data_ptr(), N, 256, phi.data_ptr(), psi.data_ptr(), 0.5, 1.0, od.data_ptr(), st)), 10)
     fl, by = 2.0 * N * N * 256 + 3 * 2.0 * N * 256 * 256, (2 * N * 256 + N * N) * 8.0
-    out.append({"kernel": "sc_plda_fast (dgemm_kernel, v_mfma_f64_16x16x4_f64; 4 GEMMs + 2 row dots)", "Ne=Nt": N, "trials": N * N, "us": s * 1e6,
+    out.append({"kernel": "sc_plda_fast (plda_prep_kernel + dgemm_nt_kernel, v_mfma_f64_16x16x4_f64; 2 launches, cached workspace)", "Ne=Nt": N, "trials": N * N, "us": s * 1e6,
                 "TFLOP/s": fl / s / 1e12, "frac_f64_peak": fl / s / 1e12 / F64_PEAK, "GB/s": by / s / 1e9, "frac_hbm": by / s / 1e9 / HBM,
                 "trials_per_s": N * N / s})
 for N in (16384, 65536):

@@ -37,6 +37,7 @@ SIGNATURES = {
     "xt_finalize": (ctypes.c_int, [_P]),
     "xt_reserve": (ctypes.c_int, [_P, _I32, _I64]),
     "xt_forward": (ctypes.c_int, [_P, _P, _I64, _P, _I32, _I64, _P, _P, _P]),
+    "xt_forward_pcm16": (ctypes.c_int, [_P, _P, _I64, _P, _I32, _I64, _P, _P, _P]),
     "xt_forward_features": (ctypes.c_int, [_P, _P, _P, _I32, _I32, _P, _P, _P]),
     "xt_features": (ctypes.c_int, [_P, _P, _I64, _P, _I32, _I64, _P, _P]),
     "xt_set_norm_embedding": (ctypes.c_int, [_P, _I32]),

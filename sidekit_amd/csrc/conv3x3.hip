@@ -164,7 +164,12 @@ __global__ __launch_bounds__(C::WM * C::WN * 64, SC ? 1 : C::OCC)
 void conv3x3_kernel(ConvArgs a) {
   using T = typename C::T;
   constexpr int NWAVES = C::WM * C::WN, NTHREADS = NWAVES * 64;
-  const int nt0 = blockIdx.y * (C::NT / 32);  // first 32-channel output tile of this workgroup (grid.y splits COUT when NT < COUT)
+  // NT < COUT (layer 4: 128 of 256 output channels per workgroup): the NY workgroups of a work item read the SAME halo tile, so
+  // they sit NY x 8 apart in a 1-D grid -- block ids b and b + 8 share an XCD (round-robin dispatch) and start together, which
+  // makes the second read of the tile an L2 hit instead of a second trip to HBM (grid.y = 2 moved 1.58 x the algorithmic bytes)
+  constexpr int NY = C::COUT / C::NT;
+  const int bidx = NY == 1 ? (int)blockIdx.x : (int)(((blockIdx.x >> 3) / NY) * 8 + (blockIdx.x & 7));
+  const int nt0 = (NY == 1 ? 0 : (int)((blockIdx.x >> 3) % NY)) * (C::NT / 32);  // first 32-channel output tile of this workgroup
   __shared__ __attribute__((aligned(1024))) unsigned char smem[C::LDS];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
@@ -175,12 +180,12 @@ void conv3x3_kernel(ConvArgs a) {
   // The grid is either one workgroup per work item or (weight-resident shapes, see RESIDENT) as many workgroups as the
   // chip holds at once, each walking every wstride-th item of its XCD's run -- neighbouring workgroups of an XCD are
   // then always on neighbouring tiles.
-  const int nwork = a.B * tiles, q8 = nwork >> 3, r8 = nwork & 7, xcd = blockIdx.x & 7;
+  const int nwork = a.B * tiles, q8 = nwork >> 3, r8 = nwork & 7, xcd = bidx & 7;
   const int wfirst = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8, wcount = q8 + (xcd < r8 ? 1 : 0);
   const int wstride = (int)(gridDim.x >> 3) + (xcd < (int)(gridDim.x & 7) ? 1 : 0);
   auto stamp = [&](int k) {  // diagnostic build path only (a.stamps == nullptr in the product)
     if (a.stamps && tid == 0) {
-      unsigned long long* sp = a.stamps + (size_t)blockIdx.x * 8;
+      unsigned long long* sp = a.stamps + (size_t)bidx * 8;
       sp[k] = __builtin_amdgcn_s_memtime();
       // slot 7: the workgroup's span on the constant 100 MHz clock (s_memrealtime) -> in-kernel shader clock = cycles / span
       if (k == 0) sp[7] = __builtin_amdgcn_s_memrealtime();
@@ -781,10 +786,10 @@ void conv3x3_kernel(ConvArgs a) {
   };
   if constexpr (RESIDENT) {
     bool first_item = true;
-    for (int wi = blockIdx.x >> 3; wi < wcount; wi += wstride)
+    for (int wi = bidx >> 3; wi < wcount; wi += wstride)
       if (do_item(wfirst + wi, first_item)) first_item = false;
   } else {  // one work item per workgroup (no loop: its invariants would cost these kernels registers)
-    if ((int)(blockIdx.x >> 3) < wcount) do_item(wfirst + (int)(blockIdx.x >> 3), true);
+    if ((bidx >> 3) < wcount) do_item(wfirst + (bidx >> 3), true);
   }
 }
 
@@ -805,7 +810,9 @@ static int launch_cfg(const ConvArgs& a, hipStream_t st) {
   constexpr int NWV = C::WM * C::WN;
   const int occ = ((a.sc_wpack && !a.sc_in) ? 1 : C::OCC) * 4 / NWV, by_lds = 160 * 1024 / C::LDS;   // the fused-shortcut kernels are compiled for one wave per SIMD
   const int resident_wgs = cu_count() * (occ < by_lds ? (occ > 0 ? occ : 1) : by_lds);
-  dim3 grid((unsigned)((C::RESIDENT && !(a.dbg & 8) && nwork > resident_wgs) ? resident_wgs : nwork), C::COUT / C::NT);
+  constexpr int NY = C::COUT / C::NT;   // workgroups per work item (output-channel split): folded into a 1-D grid, see the kernel
+  static_assert(NY == 1 || !C::RESIDENT, "persistent shapes cover all output channels");
+  dim3 grid((unsigned)(NY > 1 ? cdiv(nwork, 8) * 8 * NY : ((C::RESIDENT && !(a.dbg & 8) && nwork > resident_wgs) ? resident_wgs : nwork)), 1);
   const dim3 block(NWV * 64);
   if (a.dbg & 16) {  // tuning aid: what the runtime says about residency of the statistics-form kernel
     int nb = -1;

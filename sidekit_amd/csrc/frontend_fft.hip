@@ -35,6 +35,16 @@ __device__ inline void fft8(cf* v) {
 
 __device__ inline int pad(int i) { return i + (i >> 3); }
 
+// One utterance's samples: float32, or 16-bit PCM widened in the load as x / 32768 -- exact in f32, the very numbers the
+// reference's soundfile / torchaudio decode hands its model (sidekit/bin/extract_xvectors.py:57-70), so both entry points give
+// bit-identical features.  The selector is wave-uniform.
+struct SampleRow {
+  const void* base; long off; int pcm16;
+  __device__ inline float operator[](int i) const {
+    return pcm16 ? (float)reinterpret_cast<const short*>(base)[off + i] * (1.0f / 32768.0f) : reinterpret_cast<const float*>(base)[off + i];
+  }
+};
+
 constexpr int FFT_WAVES = 4;
 constexpr int FFT_BUF = 512 + 64;  // padded complex slots per wave
 
@@ -54,7 +64,7 @@ __global__ __launch_bounds__(FFT_WAVES * 64) void stft_power_fft_kernel(FftArgs 
     else { for (int k = lane; k < a.ldp; k += 64) prow[k] = 0.f; }
     return;
   }
-  const float* w = a.wav + (long)b * a.wav_ld;
+  const SampleRow w{a.wav, (long)b * a.wav_ld, a.pcm16};
   const int i0 = t * a.hop - 200;  // sample index of window tap 0 (centre tap 200 sits on t*hop)
   auto xw = [&](int k) {           // windowed, pre-emphasised sample of window tap k, reflect-padded at the utterance edges
     int i = i0 + k;
@@ -169,7 +179,7 @@ __global__ __launch_bounds__(FFT_WAVES * 64) void stft_power_fft2k_kernel(FftArg
     else { for (int k = lane; k < a.ldp; k += 64) prow[k] = 0.f; }
     return;
   }
-  const float* w = a.wav + (long)b * a.wav_ld;
+  const SampleRow w{a.wav, (long)b * a.wav_ld, a.pcm16};
   const int i0 = t * a.hop - 512;  // sample index of window tap 0 (centre tap 512 sits on t*hop)
   auto xw = [&](int k) {           // windowed, pre-emphasised sample of window tap k, reflect-padded at the utterance edges
     int i = i0 + k;

@@ -120,7 +120,8 @@ int launch_gemm(const GemmArgs& g, hipStream_t s);
 // ---- frontend_fft.hip ------------------------------------------------------------------------
 // |rFFT_1024(window * preemph(frame))|^2 for the log-mel front-end (n_fft 1024, win 400), one wave per frame
 struct FftArgs {
-  const float* wav; long wav_ld;
+  const void* wav; long wav_ld;                // [B][wav_ld] float32 samples, or int16 PCM (pcm16 != 0: widened as x / 32768 in the load)
+  int pcm16;
   const int* nsamples; int nsamples_uniform;   // per-utterance sample counts (device) or one value for all
   int n_fft;                                   // 1024 (window 400, log-mel front-end) or 2048 (window 1024, MFCC front-end)
   const float* window;                         // [400] / [1024]

@@ -2,11 +2,16 @@
 // per-trial cosine of sidekit/bin/compute_spk_cosine.py:18-26.
 //
 // cosine is one f32 MFMA GEMM over the already normalised rows.  PLDA keeps the reference's
-// float64 arithmetic end to end: the 256x256 algebra (Phi, Psi, constant) stays on the host, the
-// N^2 part runs here as an f64 MFMA GEMM (C = A . B^T, v_mfma_f64_16x16x4_f64) whose epilogue adds
-// the two quadratic terms and the constant, so the (Ne x Nt) matrix is written exactly once.  For
+// float64 arithmetic end to end: the 256x256 algebra (Phi, Psi, constant) stays on the host; here ONE
+// launch forms E.Psi and the two quadratic forms, and the N^2 part runs as an f64 MFMA GEMM
+// (C = A . B^T, v_mfma_f64_16x16x4_f64) whose epilogue adds the quadratic terms and the constant, so
+// the (Ne x Nt) matrix is written exactly once.  For
 // trial sets too large to materialise, sc_cosine_hist counts target / non-target scores into
 // histograms straight from the accumulators.
+#include <map>
+#include <mutex>
+#include <utility>
+
 #include "../../include/sidekit_amd.h"
 #include "kernels.h"
 
@@ -14,73 +19,195 @@ namespace sk {
 
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 
-constexpr int DT = 64, DK = 16, DLD = DK + 1;   // 64 x 64 output tile per workgroup, 16-deep k-tiles, LDS rows padded by one double
-
-// C[m][n] = alpha * (sum_k A[m][k] Bop(k,n) + rowterm[m] + colterm[n] + cst), float64 end to end on the matrix cores:
-// v_mfma_f64_16x16x4_f64 (A: lane l holds A[l & 15][l >> 4], B: B[l >> 4][l & 15], D: four doubles per lane at
-// row (l >> 4) + 4 * reg, col l & 15 -- the f64 map, which differs from the f32 one).  Four waves, each a 32 x 32 quadrant = 2 x 2
-// MFMA tiles; operands staged through LDS as [row][k] with a 17-double row stride, which makes the ds_read_b64 fragment reads
-// (16 rows x 2 k per half-wave) hit 32 different bank pairs.
+// f64 GEMM tile on the matrix cores, the core of fast / full PLDA scoring.
+//   v_mfma_f64_16x16x4_f64: A: lane l holds A[l & 15][l >> 4], B: B[l >> 4][l & 15], D: four doubles per lane at row (l >> 4) + 4 * reg,
+//   col l & 15 (the f64 map, which differs from the f32 one); 64 matrix-pipe cycles each (78.6 TFLOP/s = 32 FLOP / clk / SIMD).
+// Four waves in a 2 x 2 grid, each WT x WT MFMA tiles: WT = 2 -> 64 x 64 per workgroup (small trial sets: enough workgroups to fill 256
+// CUs), WT = 4 -> 128 x 128 (half the operand traffic per FLOP, 64 accumulator doubles per lane, two workgroups per CU).  Operands are
+// staged through LDS as [row][k] with a 17-double row stride (ds_read_b64 fragment reads: 16 rows x 2 k per half-wave land on 32
+// different bank pairs but one), the next k-tile's operands are fetched into registers (16-byte loads) while this one is multiplied.
 //   B_KN = false: B is [N][K] (C = A . B^T);  B_KN = true: B is [K][N] (C = A . B)
-template <bool B_KN>
-__global__ __launch_bounds__(256) void dgemm_kernel(const double* __restrict__ A, const double* __restrict__ B, double* __restrict__ C,
-                                                       int M, int N, int K, const double* __restrict__ rowterm,
-                                                       const double* __restrict__ colterm, double cst, double alpha) {
-  __shared__ __attribute__((aligned(16))) double As[DT * DLD];
-  __shared__ __attribute__((aligned(16))) double Bs[DT * DLD];
+constexpr int DK = 16, DLD = DK + 1;
+
+template <int WT, bool B_KN>
+__device__ inline void dgemm_tile(const double* __restrict__ A, const double* __restrict__ B, int M, int N, int K, int m0, int n0,
+                                  double* As, double* Bs, f64x4 (&acc)[WT][WT]) {
+  constexpr int T = 32 * WT;            // workgroup tile edge
+  constexpr int PA = T * DK / 2 / 256;  // double pairs per thread and operand
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1, lr = lane & 15, lk = lane >> 4;
-  const int m0 = blockIdx.y * DT, n0 = blockIdx.x * DT;
-  f64x4 acc[2][2];
+  const bool vec_a = (K & 1) == 0 && (reinterpret_cast<size_t>(A) & 15) == 0;
+  const bool vec_b = ((B_KN ? N : K) & 1) == 0 && (reinterpret_cast<size_t>(B) & 15) == 0;
+  double2 ra[PA], rb[PA];
+  auto fetch = [&](int k0) {
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = f64x4{0.0, 0.0, 0.0, 0.0};
-  for (int k0 = 0; k0 < K; k0 += DK) {
-    // stage: 64 rows x 16 k per operand, consecutive threads along the contiguous dimension of each source
-    for (int i = tid; i < DT * DK; i += 256) {
-      const int row = i / DK, kk = i % DK, m = m0 + row, k = k0 + kk;
-      As[row * DLD + kk] = (m < M && k < K) ? A[(long)m * K + k] : 0.0;
+    for (int q = 0; q < PA; ++q) {
+      const int idx = tid + 256 * q;
+      {  // A: T rows x 8 pairs along k
+        const int row = idx >> 3, kp = (idx & 7) * 2, m = m0 + row, k = k0 + kp;
+        double2 v = {0.0, 0.0};
+        if (m < M) {
+          const double* src = A + (long)m * K + k;
+          if (vec_a && k + 1 < K) v = *reinterpret_cast<const double2*>(src);
+          else { if (k < K) v.x = src[0]; if (k + 1 < K) v.y = src[1]; }
+        }
+        ra[q] = v;
+      }
       if constexpr (!B_KN) {
-        const int n = n0 + row;
-        Bs[row * DLD + kk] = (n < N && k < K) ? B[(long)n * K + k] : 0.0;
+        const int row = idx >> 3, kp = (idx & 7) * 2, n = n0 + row, k = k0 + kp;
+        double2 v = {0.0, 0.0};
+        if (n < N) {
+          const double* src = B + (long)n * K + k;
+          if (vec_b && k + 1 < K) v = *reinterpret_cast<const double2*>(src);
+          else { if (k < K) v.x = src[0]; if (k + 1 < K) v.y = src[1]; }
+        }
+        rb[q] = v;
+      } else {  // B [K][N]: 16 k x T/2 pairs along n
+        const int kk = idx / (T / 2), np = (idx % (T / 2)) * 2, n = n0 + np, k = k0 + kk;
+        double2 v = {0.0, 0.0};
+        if (k < K) {
+          const double* src = B + (long)k * N + n;
+          if (vec_b && n + 1 < N) v = *reinterpret_cast<const double2*>(src);
+          else { if (n < N) v.x = src[0]; if (n + 1 < N) v.y = src[1]; }
+        }
+        rb[q] = v;
       }
     }
-    if constexpr (B_KN) {
-      for (int i = tid; i < DT * DK; i += 256) {
-        const int kk = i / DT, col = i % DT, n = n0 + col, k = k0 + kk;
-        Bs[col * DLD + kk] = (n < N && k < K) ? B[(long)k * N + n] : 0.0;
+  };
+  auto stage = [&]() {
+#pragma unroll
+    for (int q = 0; q < PA; ++q) {
+      const int idx = tid + 256 * q;
+      const int row = idx >> 3, kp = (idx & 7) * 2;
+      As[row * DLD + kp] = ra[q].x; As[row * DLD + kp + 1] = ra[q].y;
+      if constexpr (!B_KN) { Bs[row * DLD + kp] = rb[q].x; Bs[row * DLD + kp + 1] = rb[q].y; }
+      else {
+        const int kk = idx / (T / 2), np = (idx % (T / 2)) * 2;
+        Bs[np * DLD + kk] = rb[q].x; Bs[(np + 1) * DLD + kk] = rb[q].y;
       }
     }
+  };
+#pragma unroll
+  for (int i = 0; i < WT; ++i)
+#pragma unroll
+    for (int j = 0; j < WT; ++j) acc[i][j] = f64x4{0.0, 0.0, 0.0, 0.0};
+  fetch(0);
+  for (int k0 = 0; k0 < K; k0 += DK) {
+    __syncthreads();   // every wave is done reading the previous k-tile
+    stage();
     __syncthreads();
+    if (k0 + DK < K) fetch(k0 + DK);
 #pragma unroll
     for (int kk = 0; kk < DK; kk += 4) {
-      double a[2], b[2];
+      double a[WT], b[WT];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        a[i] = As[(wm * 32 + i * 16 + lr) * DLD + kk + lk];
-        b[i] = Bs[(wn * 32 + i * 16 + lr) * DLD + kk + lk];
+      for (int i = 0; i < WT; ++i) {
+        a[i] = As[(wm * 16 * WT + i * 16 + lr) * DLD + kk + lk];
+        b[i] = Bs[(wn * 16 * WT + i * 16 + lr) * DLD + kk + lk];
       }
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < WT; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < WT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
     }
-    __syncthreads();
+  }
+}
+
+// C[m][n] = alpha * (sum_k A[m][k] B[n][k] + rowterm(m) + colterm(n) + cst); the two terms arrive as `nparts` partial sums each
+// (rowterm(m) = sum_p rowpart[p * M + m], fixed order), which is how plda_prep_kernel leaves the quadratic forms.
+template <int WT>
+__global__ __launch_bounds__(256, WT == 4 ? 2 : 4) void dgemm_nt_kernel(const double* __restrict__ A, const double* __restrict__ B, double* __restrict__ C,
+                                                          int M, int N, int K, const double* __restrict__ rowpart,
+                                                          const double* __restrict__ colpart, int nparts, double cst, double alpha) {
+  constexpr int T = 32 * WT;
+  __shared__ __attribute__((aligned(16))) double As[T * DLD];
+  __shared__ __attribute__((aligned(16))) double Bs[T * DLD];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 1, wn = wave & 1, lr = lane & 15, lk = lane >> 4;
+  const int m0 = blockIdx.y * T, n0 = blockIdx.x * T;
+  f64x4 acc[WT][WT];
+  dgemm_tile<WT, false>(A, B, M, N, K, m0, n0, As, Bs, acc);
+  double ct[WT];
+#pragma unroll
+  for (int j = 0; j < WT; ++j) {
+    const int n = n0 + wn * 16 * WT + j * 16 + lr;
+    double t = 0.0;
+    if (n < N) for (int p = 0; p < nparts; ++p) t += colpart[(long)p * N + n];
+    ct[j] = t;
   }
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < WT; ++i)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const int m = m0 + wm * 32 + i * 16 + lk + 4 * q;
+      const int m = m0 + wm * 16 * WT + i * 16 + lk + 4 * q;
       if (m >= M) continue;
-      const double rt = rowterm ? rowterm[m] : 0.0;
+      double rt = 0.0;
+      for (int p = 0; p < nparts; ++p) rt += rowpart[(long)p * M + m];
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int n = n0 + wn * 32 + j * 16 + lr;
-        if (n < N) C[(long)m * N + n] = alpha * (acc[i][j][q] + rt + (colterm ? colterm[n] : 0.0) + cst);
+      for (int j = 0; j < WT; ++j) {
+        const int n = n0 + wn * 16 * WT + j * 16 + lr;
+        if (n < N) C[(long)m * N + n] = alpha * (acc[i][j][q] + rt + ct[j] + cst);
       }
     }
+}
+
+// Everything fast PLDA needs before its N^2 product, in ONE launch (sidekit/iv_scoring.py:449-458):
+//   qpart_e[p][i] = 0.5 * sum_{n in column tile p} (E Phi)[i][n] E[i][n]      -> model_part = sum_p qpart_e[p]   (:449)
+//   qpart_t[p][j] = the same for T                                          -> seg_part                        (:450)
+//   EPsi = E . Psi                                                           (left factor of :458)
+// Grid: x = column tile of [Phi | Psi] (D/64 + D/64), y = row tile of [E ; T]; the (T rows, Psi columns) workgroups have nothing to
+// do.  The products X Phi are never written: each workgroup folds its 64 x 64 tile with the matching slice of X straight from the
+// accumulators (16-lane reduction, then the two column waves through LDS; deterministic).
+__global__ __launch_bounds__(256) void plda_prep_kernel(const double* __restrict__ E, int Ne, const double* __restrict__ Tm, int Nt, int D,
+                                                        const double* __restrict__ Phi, const double* __restrict__ Psi,
+                                                        double* __restrict__ qpart_e, double* __restrict__ qpart_t, double* __restrict__ EPsi) {
+  constexpr int WT = 2, T = 64;
+  __shared__ __attribute__((aligned(16))) double As[T * DLD];
+  __shared__ __attribute__((aligned(16))) double Bs[T * DLD];
+  __shared__ double red[2][T];
+  const int ctiles = (D + T - 1) / T, etiles = (Ne + T - 1) / T;
+  const bool psi = (int)blockIdx.x >= ctiles, is_t = (int)blockIdx.y >= etiles;
+  if (psi && is_t) return;
+  const double* X = is_t ? Tm : E;
+  const int M = is_t ? Nt : Ne;
+  const int m0 = (is_t ? (int)blockIdx.y - etiles : (int)blockIdx.y) * T, p = psi ? (int)blockIdx.x - ctiles : (int)blockIdx.x, n0 = p * T;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 1, wn = wave & 1, lr = lane & 15, lk = lane >> 4;
+  f64x4 acc[WT][WT];
+  dgemm_tile<WT, true>(X, psi ? Psi : Phi, M, D, D, m0, n0, As, Bs, acc);
+  if (psi) {
+#pragma unroll
+    for (int i = 0; i < WT; ++i)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int m = m0 + wm * 32 + i * 16 + lk + 4 * q;
+        if (m >= M) continue;
+#pragma unroll
+        for (int j = 0; j < WT; ++j) {
+          const int n = n0 + wn * 32 + j * 16 + lr;
+          if (n < D) EPsi[(long)m * D + n] = acc[i][j][q];
+        }
+      }
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < WT; ++i)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int r = wm * 32 + i * 16 + lk + 4 * q, m = m0 + r;
+      double s = 0.0;
+#pragma unroll
+      for (int j = 0; j < WT; ++j) {
+        const int n = n0 + wn * 32 + j * 16 + lr;
+        if (m < M && n < D) s = fma(acc[i][j][q], X[(long)m * D + n], s);
+      }
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o);   // the 16 lanes that share lk hold this row's 16 columns of each tile
+      if (lr == 0) red[wn][r] = s;
+    }
+  __syncthreads();
+  if (threadIdx.x < T && m0 + (int)threadIdx.x < M)
+    (is_t ? qpart_t : qpart_e)[(long)p * M + m0 + threadIdx.x] = 0.5 * (red[0][threadIdx.x] + red[1][threadIdx.x]);
 }
 
 // ---- all-pairs cosine scoring WITHOUT the score matrix (100k x 100k trials are 40 GB of float32) ---------------------
@@ -188,17 +315,6 @@ __global__ __launch_bounds__(HTHREADS) void cosine_hist_kernel(const float* __re
   }
 }
 
-// q[i] = 0.5 * sum_k X[i][k] * Y[i][k]
-__global__ void half_rowdot_kernel(const double* __restrict__ X, const double* __restrict__ Y, double* __restrict__ q, int N, int D) {
-  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (i >= N) return;
-  double s = 0.0;
-  for (int k = lane; k < D; k += 64) s = fma(X[(long)i * D + k], Y[(long)i * D + k], s);
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-  if (lane == 0) q[i] = 0.5 * s;
-}
-
 __global__ void cosine_trials_kernel(const float* __restrict__ E, const float* __restrict__ T, int D, const int* __restrict__ ei,
                                      const int* __restrict__ ti, long n, double* __restrict__ out) {
   const long k = blockIdx.x * 4L + (threadIdx.x >> 6);
@@ -294,12 +410,25 @@ __global__ void snorm_apply_kernel(float* __restrict__ S, int ne, int nt, const 
   S[i] = 0.5f * ((v - me[r]) / se[r]) + 0.5f * ((v - mt[c]) / st[c]);
 }
 
-static int dgemm(bool b_kn, const double* A, const double* B, double* C, int M, int N, int K, const double* rt, const double* ct,
-                 double cst, double alpha, hipStream_t s) {
-  const dim3 grid(cdiv(N, DT), cdiv(M, DT));
-  if (b_kn) hipLaunchKernelGGL(dgemm_kernel<true>, grid, dim3(256), 0, s, A, B, C, M, N, K, rt, ct, cst, alpha);
-  else hipLaunchKernelGGL(dgemm_kernel<false>, grid, dim3(256), 0, s, A, B, C, M, N, K, rt, ct, cst, alpha);
-  SK_HIP(hipGetLastError());
+// ---- workspace of sc_plda_fast: E . Psi (Ne x D) and the partial quadratic forms, cached per (device, stream) so that a call
+// allocates nothing in the steady state (three hipMallocAsync / hipFreeAsync pairs per call were most of a 1000 x 1000 scoring).  A
+// stream's calls are ordered, so reuse needs no further synchronisation; growth waits for that stream's earlier calls first.
+struct PldaWs { void* p = nullptr; size_t bytes = 0; };
+static std::mutex g_plda_mu;
+static std::map<std::pair<int, hipStream_t>, PldaWs> g_plda_ws;
+
+static int plda_workspace(hipStream_t st, size_t bytes, void** out) {
+  int dev = 0;
+  SK_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lock(g_plda_mu);
+  PldaWs& w = g_plda_ws[{dev, st}];
+  if (bytes > w.bytes) {
+    if (w.p) { SK_HIP(hipStreamSynchronize(st)); SK_HIP(hipFree(w.p)); w.p = nullptr; w.bytes = 0; }
+    const size_t want = bytes + bytes / 4;
+    SK_HIP(hipMalloc(&w.p, want));
+    w.bytes = want;
+  }
+  *out = w.p;
   return SK_OK;
 }
 
@@ -320,24 +449,22 @@ int sc_plda_fast(const double* d_E, int32_t Ne, const double* d_T, int32_t Nt, i
                  double cst, double scaling, double* d_out, void* stream) {
   SK_CHECK(d_E && d_T && d_Phi && d_Psi && d_out && Ne > 0 && Nt > 0 && D > 0, SK_EARG, "sc_plda_fast: bad arguments");
   hipStream_t st = (hipStream_t)stream;
-  double *tmp = nullptr, *qe = nullptr, *qt = nullptr;
-  const int Nmax = Ne > Nt ? Ne : Nt;
-  SK_HIP(hipMallocAsync((void**)&tmp, (size_t)Nmax * D * 8, st));
-  SK_HIP(hipMallocAsync((void**)&qe, (size_t)Ne * 8, st));
-  SK_HIP(hipMallocAsync((void**)&qt, (size_t)Nt * 8, st));
-  int rc = SK_OK;
-  do {
-    // model_part / seg_part = 0.5 * diag(X Phi X')   (iv_scoring.py:449-450)
-    if ((rc = dgemm(true, d_E, d_Phi, tmp, Ne, D, D, nullptr, nullptr, 0.0, 1.0, st))) break;
-    hipLaunchKernelGGL(half_rowdot_kernel, dim3(cdiv(Ne, 4)), dim3(256), 0, st, tmp, d_E, qe, Ne, D);
-    if ((rc = dgemm(true, d_T, d_Phi, tmp, Nt, D, D, nullptr, nullptr, 0.0, 1.0, st))) break;
-    hipLaunchKernelGGL(half_rowdot_kernel, dim3(cdiv(Nt, 4)), dim3(256), 0, st, tmp, d_T, qt, Nt, D);
-    // scoremat = (model_part[:, None] + seg_part + cst + E Psi T') * scaling   (:458-460)
-    if ((rc = dgemm(true, d_E, d_Psi, tmp, Ne, D, D, nullptr, nullptr, 0.0, 1.0, st))) break;
-    rc = dgemm(false, tmp, d_T, d_out, Ne, Nt, D, qe, qt, cst, scaling, st);
-  } while (0);
-  (void)hipFreeAsync(tmp, st); (void)hipFreeAsync(qe, st); (void)hipFreeAsync(qt, st);
-  return rc;
+  const int ctiles = cdiv(D, 64);
+  const size_t n_epsi = ((size_t)Ne * D + 1) & ~(size_t)1, n_qe = (size_t)ctiles * Ne, n_qt = (size_t)ctiles * Nt;
+  void* ws = nullptr;
+  SK_TRY(plda_workspace(st, (n_epsi + n_qe + n_qt) * 8, &ws));
+  double* epsi = (double*)ws;
+  double* qe = epsi + n_epsi;
+  double* qt = qe + n_qe;
+  // 1) model_part / seg_part = 0.5 * diag(X Phi X') as per-column-tile partials, and E . Psi   (iv_scoring.py:449-450,458)
+  hipLaunchKernelGGL(plda_prep_kernel, dim3(2 * ctiles, cdiv(Ne, 64) + cdiv(Nt, 64)), dim3(256), 0, st, d_E, Ne, d_T, Nt, D, d_Phi, d_Psi, qe, qt, epsi);
+  SK_HIP(hipGetLastError());
+  // 2) scoremat = (model_part[:, None] + seg_part + cst + (E Psi) T') * scaling   (:458-460)
+  const bool big = (long)cdiv(Ne, 128) * cdiv(Nt, 128) >= 512;   // two 128 x 128 workgroups per CU and still two rounds of them
+  if (big) hipLaunchKernelGGL(dgemm_nt_kernel<4>, dim3(cdiv(Nt, 128), cdiv(Ne, 128)), dim3(256), 0, st, epsi, d_T, d_out, Ne, Nt, D, qe, qt, ctiles, cst, scaling);
+  else hipLaunchKernelGGL(dgemm_nt_kernel<2>, dim3(cdiv(Nt, 64), cdiv(Ne, 64)), dim3(256), 0, st, epsi, d_T, d_out, Ne, Nt, D, qe, qt, ctiles, cst, scaling);
+  SK_HIP(hipGetLastError());
+  return SK_OK;
 }
 
 int sc_topk_stats(const float* d_scores, int32_t n_rows, int32_t n_cols, int32_t k, float* d_mean, float* d_std, void* stream) {

@@ -546,7 +546,7 @@ static int ring_end(xt_handle* h, hipStream_t st) {
   return SK_OK;
 }
 
-static int frontend_rows(xt_handle* h, const float* d_wav, int64_t wav_ld, const BatchMeta& m, float* d_feat_rows, hipStream_t st) {
+static int frontend_rows(xt_handle* h, const void* d_wav, int pcm16, int64_t wav_ld, const BatchMeta& m, float* d_feat_rows, hipStream_t st) {
   const FrontCfg& f = h->fc;
   const int M = m.R ? m.R : m.B * m.T;
   const bool mfcc = h->cfg.arch == XT_ARCH_TDNN;
@@ -557,7 +557,7 @@ static int frontend_rows(xt_handle* h, const float* d_wav, int64_t wav_ld, const
     // 1) |rFFT(window * preemph(frame))|^2, one wavefront per frame (frontend_fft.hip)
     FftArgs fa;
     fa.n_fft = f.n_fft;
-    fa.wav = d_wav; fa.wav_ld = wav_ld; fa.nsamples = m.d_nsamples; fa.nsamples_uniform = m.nsamples_uniform; fa.window = h->d_window;
+    fa.wav = d_wav; fa.pcm16 = pcm16; fa.wav_ld = wav_ld; fa.nsamples = m.d_nsamples; fa.nsamples_uniform = m.nsamples_uniform; fa.window = h->d_window;
     fa.tw512 = h->d_tw512; fa.tw1024 = h->d_tw1024; fa.P = (float*)h->ws_S.p; fa.ldp = h->nbp; fa.M = M; fa.t_max = m.T; fa.hop = f.hop;
     fa.row_b = m.d_row_b; fa.row_t = m.d_row_t; fa.preemph = 0.97f;
     SK_CHECK((size_t)M * h->nbp * 4 <= h->ws_S.bytes, SK_EWORKSPACE, "spectrum workspace too small (xt_reserve)");
@@ -572,6 +572,7 @@ static int frontend_rows(xt_handle* h, const float* d_wav, int64_t wav_ld, const
     p.a_mode = A_PLAIN; p.A = h->ws_S.p; p.lda = h->nbp; p.a_rows = M;
   } else {
     // 1) frames x DFT basis -> [re | im]   (A/B form of the MFCC front-end: n_fft 2048, win 1024)
+    SK_CHECK(!pcm16, SK_EARG, "the DFT-GEMM A/B form of the MFCC front-end (SIDEKIT_AMD_MFCC_DFT_GEMM) takes float32 samples only");
     GemmArgs g = gemm_args();
     g.a_mode = A_FRAMES; g.A = d_wav; g.wav_ld = wav_ld; g.window = h->d_window; g.nsamples = m.d_nsamples;
     g.nsamples_uniform = m.nsamples_uniform; g.hop = f.hop; g.t_max = m.T; g.row_b = m.d_row_b; g.row_t = m.d_row_t;
@@ -961,19 +962,29 @@ static int check_run(xt_handle* h, int B, int64_t L_samples) {
   return SK_OK;
 }
 
-int xt_forward(xt_handle* h, const float* d_wav, int64_t wav_ld, const int32_t* h_nsamples, int32_t B, int64_t L, float* d_emb,
-               float* d_logits, void* stream) {
+static int forward_wav(xt_handle* h, const void* d_wav, int pcm16, int64_t wav_ld, const int32_t* h_nsamples, int32_t B, int64_t L,
+                       float* d_emb, float* d_logits, void* stream) {
   SK_TRY(check_run(h, B, L));
   SK_CHECK(d_wav && d_emb && wav_ld >= L, SK_EARG, "xt_forward: bad buffers");
   hipStream_t st = (hipStream_t)stream;
   BatchMeta m;
   SK_TRY(make_meta(h, h_nsamples, B, L, true, m, st));
   float* feat = (float*)h->ws_feat.p;
-  SK_TRY(frontend_rows(h, d_wav, wav_ld, m, feat, st));
+  SK_TRY(frontend_rows(h, d_wav, pcm16, wav_ld, m, feat, st));
   const int M = m.R ? m.R : m.B * m.T;
   SK_TRY(tap(h, "feats", feat, (size_t)M * h->fc.n_out * 4, st));
   if (h->cfg.arch == XT_ARCH_HALFRESNET34) return half_from_feats(h, feat, (long)m.T * 80, 1, 80, m, d_emb, d_logits, st);
   return tdnn_from_rows(h, feat, m, d_emb, d_logits, st);
+}
+
+int xt_forward(xt_handle* h, const float* d_wav, int64_t wav_ld, const int32_t* h_nsamples, int32_t B, int64_t L, float* d_emb,
+               float* d_logits, void* stream) {
+  return forward_wav(h, d_wav, 0, wav_ld, h_nsamples, B, L, d_emb, d_logits, stream);
+}
+
+int xt_forward_pcm16(xt_handle* h, const int16_t* d_pcm, int64_t pcm_ld, const int32_t* h_nsamples, int32_t B, int64_t L, float* d_emb,
+                     float* d_logits, void* stream) {
+  return forward_wav(h, d_pcm, 1, pcm_ld, h_nsamples, B, L, d_emb, d_logits, stream);
 }
 
 int xt_forward_features(xt_handle* h, const float* d_feats, const int32_t* h_frames, int32_t B, int32_t T, float* d_emb,
@@ -1002,7 +1013,7 @@ int xt_features(xt_handle* h, const float* d_wav, int64_t wav_ld, const int32_t*
   BatchMeta m;
   SK_TRY(make_meta(h, h_nsamples, B, L, true, m, st));
   float* feat = (float*)h->ws_feat.p;
-  SK_TRY(frontend_rows(h, d_wav, wav_ld, m, feat, st));
+  SK_TRY(frontend_rows(h, d_wav, 0, wav_ld, m, feat, st));
   const int T = 1 + (int)(L / h->fc.hop);
   RowSpan rs{m.d_offsets, m.T, m.lens, 0, 0};
   hipLaunchKernelGGL(rows_to_bft_kernel, dim3(B), dim3(256), 0, st, feat, d_feats_out, h->fc.n_out, T, rs);

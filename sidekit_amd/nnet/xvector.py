@@ -131,14 +131,15 @@ class Xtractor:
     def forward(self, x, is_eval=False, target=None, norm_embedding=True, lengths=None):
         """Reference ``forward`` (xvector.py:876-907) for extraction.
 
-        :param x: float32 waveform ``(L,)`` or ``(B, L)`` on the model's device
+        :param x: float32 waveform ``(L,)`` or ``(B, L)`` on the model's device -- or int16 PCM as the files hold it, which the
+            front-end kernel widens in its load (``xt_forward_pcm16``: the same numbers as ``x.float() / 32768``, no cast kernel)
         :param lengths: optional per-utterance sample counts for a zero-padded batch; each row is then
             processed exactly as if run alone (no padding semantics exist in the reference)
         :return: ``(s*cos logits (B, n_spk), x-vectors (B, E))`` for ``loss='aam'``; x-vectors for ``'cce'``
         """
         if not is_eval or target is not None:
             raise NotImplementedError("sidekit_amd.Xtractor runs extraction only: call with is_eval=True and no target")
-        x = self._check_input(x)
+        x = self._check_input(x, pcm16_ok=True)
         B, L = x.shape
         h = self._handle()
         self._reserve(h, B, L)
@@ -147,8 +148,9 @@ class Xtractor:
         emb = torch.empty((B, self.embedding_size), dtype=torch.float32, device=x.device)
         logits = torch.empty((B, int(self.speaker_number)), dtype=torch.float32, device=x.device) if self.loss == "aam" else None
         lens = self._lengths(lengths, B, L)
-        _lib.check(lib.xt_forward(h, x.data_ptr(), x.stride(0) if B > 1 else L, _ptr(lens), B, L, emb.data_ptr(),
-                                  logits.data_ptr() if logits is not None else None, self._stream(x)))
+        entry = lib.xt_forward_pcm16 if x.dtype == torch.int16 else lib.xt_forward
+        _lib.check(entry(h, x.data_ptr(), x.stride(0) if B > 1 else L, _ptr(lens), B, L, emb.data_ptr(),
+                         logits.data_ptr() if logits is not None else None, self._stream(x)))
         return (logits, emb) if self.loss == "aam" else emb
 
     def forward_features(self, feats, frames=None, norm_embedding=True):
@@ -222,7 +224,7 @@ class Xtractor:
         for top in ("sequence_network", "stat_pooling", "before_speaker_embedding", "after_speaker_embedding"):
             setattr(self, top, _Params(**groups.get(top, {})))
 
-    def _check_input(self, x, dims=2):
+    def _check_input(self, x, dims=2, pcm16_ok=False):
         if not torch.is_tensor(x):
             raise TypeError("input must be a torch tensor")
         if self.device.type != "cuda":
@@ -233,7 +235,7 @@ class Xtractor:
             raise RuntimeError(f"expected a {dims - 1}-D or {dims}-D input, got shape {tuple(x.shape)}")
         if x.device != self.device:
             raise RuntimeError(f"input is on {x.device} but the model is on {self.device}")
-        if x.dtype != torch.float32:
+        if x.dtype != torch.float32 and not (pcm16_ok and x.dtype == torch.int16):
             x = x.float()
         if x.stride(-1) != 1 or (dims == 3 and not x.is_contiguous()):
             x = x.contiguous()

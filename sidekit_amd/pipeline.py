@@ -12,9 +12,10 @@ host side has to run beside the GPU, not in front of it.  ``StreamingExtractor``
            interpreter lock, no intermediate copy) -- 16-bit audio stays int16 all the way to the device (half the PCIe
            bytes, no host conversion pass) -- while the main thread launches earlier batches;
   copy     host -> device on a copy stream; the forward waits on the copy's event, not on the host;
-  compute  int16 -> float32 / 32768 (exact, the same numbers as the host conversion), ``Xtractor.forward``, embeddings
-           back into pinned memory with a non-blocking copy; the host collects a batch only when ``pending`` newer ones
-           are already queued behind it.
+  compute  ``Xtractor.forward`` on the int16 rows themselves (``xt_forward_pcm16``: the STFT kernel's load widens them as
+           ``x / 32768``, exact, the same numbers as the host conversion -- no cast kernel, no float copy of the batch),
+           embeddings back into pinned memory with a non-blocking copy; the host collects a batch only when ``pending``
+           newer ones are already queued behind it.
 
 Memory is bounded by one window of decoded utterances and ``pending + stage_ahead + 1`` staging buffers, whatever the corpus.
 On a CPU device (tests of the plumbing) the same code runs without streams.
@@ -279,11 +280,8 @@ class StreamingExtractor:
                 dev.copy_(host, non_blocking=True)
                 slot.copied.record(self.copy_stream)
             compute.wait_event(slot.copied)
-        x = dev
-        if as_int16:
-            x = x.to(torch.float32) * (1.0 / 32768.0)           # exact: the host conversion divides by the same power of two
-        with torch.no_grad():
-            out = self.model(x, is_eval=True, norm_embedding=self.norm_embedding, lengths=lens)
+        with torch.no_grad():                                   # int16 rows go in as they are: the front-end kernel widens them in its load
+            out = self.model(dev, is_eval=True, norm_embedding=self.norm_embedding, lengths=lens)
         emb = out[1] if isinstance(out, tuple) else out
         oh = slot.out(max(rows, self.batch_size), emb.shape[1])
         oh[:rows].copy_(emb, non_blocking=self.cuda)

@@ -60,6 +60,39 @@ def test_config1_wav_scp_batch1_through_the_cli(gpu, ex, tmp_path, tag):
         assert abs(float(numpy.linalg.norm(got[k])) - 1.0) < 1e-5
 
 
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_pcm16_entry_is_bit_identical_to_the_float_entry(gpu, ex, dtype):
+    """`xt_forward_pcm16` (int16 rows widened inside the STFT kernel's load) against `xt_forward` on `pcm.float() / 32768`: the
+    three egs/examples_decode wavs alone (batch 1, as extract_xvectors.py:146 calls the model) and as one ragged batch, plus the
+    TDNN front-end; x-vectors and logits must be the SAME BITS, and match the reference embeddings."""
+    n_spk = int(ex["n_spk"])
+    model = Xtractor(n_spk, model_archi="halfresnet34", loss="aam", seed=int(ex["seed"])).to(gpu).eval()
+    model.compute_dtype = dtype
+    keys = [str(k) for k in ex["keys"]]
+    pcms = [torch.from_numpy(ex[f"pcm16_{k}"].astype(numpy.int16)) for k in keys]
+    for k, pcm in zip(keys, pcms):
+        lg_i, e_i = model(pcm.to(gpu), is_eval=True)
+        lg_f, e_f = model((pcm.float() / 32768.0).to(gpu), is_eval=True)
+        assert torch.equal(e_i, e_f) and torch.equal(lg_i, lg_f), k
+        if dtype == "fp32":
+            assert rel(e_i, ex[f"emb_full_{k}_unpinned_frontend"]) < TOL
+    lens = [p.shape[0] for p in pcms]
+    batch = torch.zeros(3, max(lens), dtype=torch.int16)
+    for r, p in enumerate(pcms):
+        batch[r, :lens[r]] = p
+    batch[0, lens[0]:] = 12345          # padding is never read: rows are cut at their own length (SURVEY N2)
+    _, e_i = model(batch.to(gpu), is_eval=True, lengths=lens)
+    _, e_f = model((batch.float() / 32768.0).to(gpu), is_eval=True, lengths=lens)
+    assert torch.equal(e_i, e_f)
+    if dtype == "fp32":
+        for r, k in enumerate(keys):
+            assert rel(e_i[r], ex[f"emb_full_{k}_unpinned_frontend"]) < TOL
+        tdnn = Xtractor(n_spk, model_archi="xvector", loss="aam", seed=4321).to(gpu).eval()
+        _, t_i = tdnn(batch.to(gpu), is_eval=True, lengths=lens)
+        _, t_f = tdnn((batch.float() / 32768.0).to(gpu), is_eval=True, lengths=lens)
+        assert torch.equal(t_i, t_f)
+
+
 def test_config1_features_seam_is_pinned(gpu, ex):
     """The same six targets entered after the front-end: oracle features (CPU) -> forward_features on the GPU.  No front-end
     of the build is involved on either side, so this is the pinned half of fixture set (ii)."""

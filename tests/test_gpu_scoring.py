@@ -191,7 +191,8 @@ def test_asnorm_golden_and_large(gpu, golden_dir):
 def test_f64_mfma_gemm_ragged_shapes(gpu):
     """sc_plda_fast on sizes that are not multiples of the 64 x 64 x 16 tile (v_mfma_f64_16x16x4_f64 path) vs float64 numpy."""
     rs = numpy.random.RandomState(8)
-    for Ne, Nt, D in ((100, 77, 50), (1, 1, 4), (65, 130, 256), (64, 64, 17)):
+    # (2900, 2950, 36) takes the 128 x 128-tile kernel (>= 512 such tiles), the others the 64 x 64 one; odd D = scalar loads
+    for Ne, Nt, D in ((100, 77, 50), (1, 1, 4), (65, 130, 256), (64, 64, 17), (2900, 2950, 36), (2817, 2900, 33)):
         E, T = rs.randn(Ne, D), rs.randn(Nt, D)
         A = rs.randn(D, D)
         Phi, Psi = -(A @ A.T) / D, rs.randn(D, D) / D
@@ -200,6 +201,15 @@ def test_f64_mfma_gemm_ragged_shapes(gpu):
                       + 0.37 + E @ Psi @ T.T)
         assert got.dtype == numpy.float64 and got.shape == (Ne, Nt)
         assert numpy.abs(got - want).max() <= 1e-11 * max(1.0, numpy.abs(want).max()), (Ne, Nt, D)
+    # operands that start 8 bytes off a 16-byte boundary (a view into a larger buffer): the 16-byte loads must not be taken
+    flat = torch.as_tensor(rs.randn(1 + 70 * 50 + 90 * 50), device=gpu)
+    E, T = flat[1:1 + 70 * 50].view(70, 50), flat[1 + 70 * 50:].view(90, 50)
+    assert E.data_ptr() % 16 == 8
+    Ph, Ps = rs.randn(50, 50) / 50, rs.randn(50, 50) / 50
+    got = iv_scoring.plda_matrix_device(E, T, Ph, Ps, 0.1, 1.0).cpu().numpy()
+    En, Tn = E.cpu().numpy(), T.cpu().numpy()
+    want = (0.5 * numpy.einsum("ik,kl,il->i", En, Ph, En)[:, None] + 0.5 * numpy.einsum("jk,kl,jl->j", Tn, Ph, Tn)[None, :] + 0.1 + En @ Ps @ Tn.T)
+    assert numpy.abs(got - want).max() <= 1e-11 * max(1.0, numpy.abs(want).max())
 
 
 def test_device_resident_scoring(gpu):

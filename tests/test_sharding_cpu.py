@@ -73,6 +73,7 @@ class _StubXtractor:
     compute_dtype = "fp32"
 
     def __call__(self, x, is_eval=False, norm_embedding=True, lengths=None):
+        x = x.float() / 32768.0 if x.dtype == torch.int16 else x
         rows = [torch.stack([x[r, :n].sum(), torch.tensor(float(n)), x[r, 0], x[r, n - 1]]) for r, n in enumerate(lengths)]
         return None, torch.stack(rows).float()
 
