@@ -20,6 +20,14 @@ prints ONE JSON line.  Two extra objects ride on that line:
   cpu_baseline the oracle's CPU restatement of the same forward, timed on this box's host cores
                on a bounded sample at batch 16 and batch 1 (rank 0, N = 1 only).
 
+The timed region runs the PRODUCT configuration: the two-lane forward (a batch of >= 128 utterances goes as two halves on two
+HIP streams, `xt_set_lanes`), in which kernels of the two halves overlap and one kernel's duration says nothing about that
+kernel.  The roofline object therefore comes from a second region of the same K steps with the lanes serialised
+(`roofline.measured_in` says so; `--lanes 1` runs everything serial, then it IS the timed region), and
+`profiles/` holds the rocprofv3 trace of the serial run.  `roofline.traffic` is not observed by this run: it is replayed
+from `profiles/traffic.json` (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command), `traffic_source` names the file
+and its capture.
+
 `--gpus N` (N > 1) started WITHOUT torch.distributed.run in the environment launches its N ranks
 itself: a fresh `python -m torch.distributed.run ... bench.py` child is created before this process
 has touched the GPU, its output is relayed and its exit code returned.  `--dry-run` replaces the GPU
@@ -102,11 +110,13 @@ def roofline(prof, B, T, dtype, per_class_ms=None):
     convs = {k: v for k, v in prof.items() if k in CONV_SHAPES and v[1]}
     if not convs:
         return None
-    traffic = {}
+    traffic, traffic_source = {}, None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         with open(tpath) as f:
-            traffic = json.load(f).get(dtype, {})
+            tj = json.load(f)
+        traffic = tj.get(dtype, {})
+        traffic_source = "replayed from profiles/traffic.json, not observed by this run: " + tj.get("_note", "")
     order = sorted(convs, key=lambda k: -convs[k][0])
     r = class_roofline(order[0], *convs[order[0]], B, T, dtype, traffic)
     if len(order) > 1:
@@ -126,7 +136,24 @@ def roofline(prof, B, T, dtype, per_class_ms=None):
             r["trunk"] = {"frac_time_weighted": t_bound / t_meas, "roofline_ms_per_step": t_bound, "measured_ms_per_step": t_meas,
                           "note": "sum over trunk convolution classes of launches x max(FLOPs / MFMA peak, bytes / HBM peak) over their measured time"}
     r["per_class_ms_per_step"] = None
+    r["traffic_source"] = traffic_source
     return r
+
+
+def tdnn_roofline(prof, frames):
+    """BASELINE configs[3]: the TDNN's five dilated conv1d layers run as `gemm_kernel<LoadPlain>` launches on the exact-f32 MFMA.
+    Algorithmic FLOPs per utterance of T' frames: 2 * [204800 (T'-4) + 786432 (T'-8) + 1835008 (T'-14)], summed
+    over the batch's own frame counts; per launch = a fifth of it (one launch per layer)."""
+    ms, n = prof.get("tdnn", (0.0, 0))
+    if not n:
+        return None
+    flops = sum(2.0 * (204800 * (t - 4) + 786432 * (t - 8) + 1835008 * (t - 14)) for t in frames)
+    per_forward_ms = ms / (n / 5.0)
+    ach = flops / (per_forward_ms * 1e-3) / 1e12
+    return {"bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TF, "traffic": None,
+            "traffic_source": None, "kernel": "gemm_kernel<LoadPlain> (TDNN conv1..conv5 as dilated implicit GEMMs, v_mfma_f32_32x32x2_f32)",
+            "launch_us": ms / n * 1e3, "launches": int(n), "alg_flops_per_launch": flops / 5.0,
+            "alg_flops_per_forward": flops, "tdnn_gemm_ms_per_step": per_forward_ms}
 
 
 def cpu_model():
@@ -140,9 +167,10 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline(seconds, budget_s=20.0):
-    """The oracle (torch-CPU restatement of the reference forward) on this box's host cores: batch 16 and batch 1
-    (SURVEY 8d), core count and CPU model stated."""
+def cpu_baseline(seconds, budget_s=24.0, arch="halfresnet34", lens=None):
+    """The oracle (torch-CPU restatement of the reference forward) on this box's host cores: batch 16 and batch 1 on a
+    one-GPU box's CPU share (16 threads), then batch 16 once more on EVERY visible core; core counts and CPU model stated.
+    TDNN (configs[3]): the first utterances of the ragged batch, one forward per utterance as the reference would run them."""
     import torch
     from oracle import xvector as oxv
     from sidekit_amd.nnet.weights import seeded_state_dict
@@ -151,26 +179,43 @@ def cpu_baseline(seconds, budget_s=20.0):
         visible = len(os.sched_getaffinity(0))
     except Exception:
         pass
-    cores = min(visible, 16)  # a one-GPU box's CPU share; more threads only oversubscribe the intra-op pool
-    torch.set_num_threads(cores)
-    sd = seeded_state_dict("halfresnet34", 7205, seed=1234)
+    cores = min(visible, 16)  # a one-GPU box's CPU share; more threads mostly oversubscribe the intra-op pool (the all-cores figure shows it)
     rates, samples = {}, []
-    for B, share in ((16, 0.65), (1, 0.35)):
+    if arch == "halfresnet34":
+        sd = seeded_state_dict("halfresnet34", 7205, seed=1234)
+        fwd = lambda w: oxv.halfresnet34_forward(w, sd)
+        plan = ((16, cores, 0.5), (1, cores, 0.3), (1, visible, 0.2))
+    else:
+        sd = seeded_state_dict("xvector", 7205, loss="aam", seed=1234)
+        fwd = lambda w: oxv.tdnn_forward(w, sd)
+        plan = ((1, cores, 0.6), (1, visible, 0.4))
+    for B, threads, share in plan:
+        torch.set_num_threads(threads)
         torch.manual_seed(0)
-        wav = 0.1 * torch.randn(B, int(seconds * 16000))
+        if lens is None:
+            batches = [0.1 * torch.randn(B, int(seconds * 16000))]
+        else:
+            batches = [0.1 * torch.randn(1, n) for n in lens[:64]]
         with torch.no_grad():
-            oxv.halfresnet34_forward(wav, sd)  # warm-up
+            if threads == cores:
+                fwd(batches[0])  # warm-up (the all-cores leg is one-shot: hundreds of threads on a 16-core share thrash for seconds per forward)
             t0 = time.perf_counter()
-            it = 0
+            it = done = 0
             while time.perf_counter() - t0 < budget_s * share and it < 64:
-                oxv.halfresnet34_forward(wav, sd)
+                done += fwd(batches[it % len(batches)])[1].shape[0]
                 it += 1
             dt = time.perf_counter() - t0
-        rates[B] = B * it / dt
-        samples.append(f"{it} batches of {B}")
-    return {"value": max(rates.values()), "unit": "x-vectors/s", "cores": cores, "kind": "port", "cores_visible": visible, "cpu_model": cpu_model(),
-            "value_batch1": rates[1], "value_batch16": rates[16],
-            "sample": f"{' and '.join(samples)} synthetic {seconds:g} s utterances, fp32, torch-CPU oracle (oracle/xvector.py), {cores} threads"}
+        rates[(B, threads)] = done / dt
+        samples.append(f"{it} batches of {B} on {threads} threads")
+    torch.set_num_threads(cores)
+    best = max(v for (b, t), v in rates.items() if t == cores)
+    out = {"value": best, "unit": "x-vectors/s", "cores": cores, "kind": "port", "cores_visible": visible, "cpu_model": cpu_model(),
+           "value_all_cores": rates.get((1, visible)), "cores_all": visible,
+           "sample": f"{'; '.join(samples)}: synthetic " + (f"{seconds:g} s" if lens is None else "2-10 s") +
+                     f" utterances, fp32, torch-CPU oracle (oracle/xvector.py)"}
+    if arch == "halfresnet34":
+        out.update(value_batch1=rates[(1, cores)], value_batch16=rates[(16, cores)])
+    return out
 
 
 def free_port():
@@ -247,6 +292,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--arch", default="halfresnet34", choices=["halfresnet34", "xvector"])
     ap.add_argument("--ragged", action="store_true", help="variable-length 2-10 s utterances (BASELINE configs[3] with --arch xvector --dtype fp32 --batch 512)")
+    ap.add_argument("--lanes", type=int, default=0, choices=[0, 1, 2], help="0: the library default (two-lane forward), 1: serial, 2: two lanes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--dry-run", action="store_true", help="CPU/gloo stand-in of the loop (plumbing test, not a measurement)")
@@ -309,49 +355,90 @@ def main():
         while in_flight:
             in_flight.pop(0)[0].wait()
 
-    # Measurement plan: an event pair per kernel launch costs ~2 us of stream time (150 pairs per step = 4-6 % of the
-    # step), so the per-class table comes from the LAST (up to 3) warmup steps with every class bracketed, and the timed
-    # region brackets only the two largest classes -- the ones the roofline object is about.
-    per_class, focus, n_prof = None, None, 0
-    n_prof_warm = 0 if args.no_profile else min(3, args.warmup)
+    if args.lanes:
+        model.set_lanes(args.lanes)
+    model(wavs[0], is_eval=True, lengths=lens)          # creates the handle and reserves the workspace (both lanes)
+    lanes = model.get_lanes() if (args.arch == "halfresnet34" and B >= 128) else 1
+
+    def timed_region(n_steps):
+        drain()
+        torch.cuda.synchronize(dev)
+        if use_dist:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(n_steps):
+            e = step()
+        drain()
+        torch.cuda.synchronize(dev)
+        if use_dist:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+        return time.perf_counter() - t0, e
+
+    # Measurement plan.  An event pair per kernel launch costs ~2 us of stream time (150 pairs per step = 4-6 % of the step), and
+    # with two lanes a kernel's duration includes whatever the other lane ran beside it.  So: (1) W warmup + exactly K timed steps
+    # in the product configuration -> `value`; when that configuration is serial, the two largest trunk classes are bracketed in
+    # it (picked from the last warmup steps, every class bracketed).  (2) Two lanes: the lanes are serialised AFTER the timed
+    # region, 3 steps with every class bracketed give the per-class table, K more steps with the two largest classes bracketed
+    # give the roofline object.
+    per_class, focus, n_prof, prof, serial_ms = None, None, 0, None, None
+    profile = not args.no_profile
+
+    def pick_focus(prof_w, n):
+        pc = {k: round(v[0] / n, 4) for k, v in prof_w.items()}
+        convs = {k: v for k, v in prof_w.items() if k in CONV_SHAPES}
+        return pc, (sorted(convs, key=lambda k: -convs[k][0])[:2] if convs else None)
+
+    n_prof_warm = min(3, args.warmup) if (profile and lanes == 1) else 0
     for i in range(args.warmup):
         if n_prof_warm and i == args.warmup - n_prof_warm:
             model.set_profile(True)
             model.get_profile(reset=True)
         step()
-    if not args.no_profile:
-        if n_prof_warm:
-            prof_w = model.get_profile(reset=True)
-            per_class = {k: round(v[0] / n_prof_warm, 4) for k, v in prof_w.items()}
-            convs = {k: v for k, v in prof_w.items() if k in CONV_SHAPES}
-            focus = sorted(convs, key=lambda k: -convs[k][0])[:2] if convs else None   # the two co-dominant classes
-            n_prof = n_prof_warm
-        if focus:
-            model.set_profile(True, slots=focus)
-        else:
-            model.set_profile(True)          # no warmup to pick a class from: bracket everything in the timed region
+    if n_prof_warm:
+        per_class, focus = pick_focus(model.get_profile(reset=True), n_prof_warm)
+        n_prof = n_prof_warm
+    if profile and lanes == 1:
+        model.set_profile(True, slots=focus) if focus else model.set_profile(True)
         model.get_profile(reset=True)
-    drain()
-    torch.cuda.synchronize(dev)
-    if use_dist:
-        dist.barrier()
-        torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        emb = step()
-    drain()
-    torch.cuda.synchronize(dev)
-    if use_dist:
-        dist.barrier()
-        torch.cuda.synchronize(dev)
-    dt = time.perf_counter() - t0
+    dt, emb = timed_region(args.steps)
     assert bool(torch.isfinite(emb).all()), "non-finite x-vectors"
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         assert torch.equal(gathered[(counter[0] - 1) % 2][rank * B:(rank + 1) * B], emb), "all-gather returned a different block for this rank"
     dt = t.item()
-
+    if profile and lanes == 1:
+        prof = model.get_profile(reset=True)
+        measured_in = "the timed region (serial lanes)"
+    elif profile and rank == 0:
+        def step():          # rank 0 alone from here on: the forward without the collective
+            counter[0] += 1
+            return model(wavs[counter[0] % len(wavs)], is_eval=True, lengths=lens)[1]
+        model.set_lanes(1)
+        step()
+        model.set_profile(True)
+        model.get_profile(reset=True)
+        for _ in range(3):
+            step()
+        per_class, focus = pick_focus(model.get_profile(reset=True), 3)
+        n_prof = 3
+        model.set_profile(True, slots=focus) if focus else model.set_profile(True)
+        model.get_profile(reset=True)
+        drain()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        drain()
+        torch.cuda.synchronize(dev)
+        serial_ms = (time.perf_counter() - t0) / args.steps * 1e3
+        prof = model.get_profile(reset=True)
+        model.set_profile(False)
+        model.set_lanes(lanes)
+        measured_in = (f"a second region of {args.steps} steps with the lanes serialised (xt_set_lanes 1, {serial_ms:.3f} ms per step), run after the "
+                       f"timed region: in the {lanes}-lane timed region kernels of the two half batches overlap")
     if rank == 0:
         T = 1 + L // (160 if args.arch == "halfresnet34" else 512)
         out = {
@@ -364,19 +451,27 @@ def main():
                        "batch_per_gpu": B, "samples_per_utt": L, "frames_per_utt": T, "resident_input_batches": len(wavs),
                        "parallelism": f"utterance-sharded x{world}" + (" + RCCL all-gather of x-vectors" if use_dist else "")},
         }
-        if not args.no_profile:
-            prof = model.get_profile(reset=True)   # timed region: the two largest classes only (or all, see above)
-            r = roofline(prof, B, T, dtype, per_class) if args.arch == "halfresnet34" else None
+        out["config"]["lanes"] = lanes
+        if profile and prof is not None:
+            if args.arch == "halfresnet34":
+                r = roofline(prof, B, T, dtype, per_class)
+            else:
+                r = tdnn_roofline(prof, [1 + n // 512 for n in (lens or [L] * B)])
             if r is not None:
-                if per_class is None:
-                    per_class = {k: round(v[0] / args.steps, 4) for k, v in prof.items()}
-                    r["per_class_source"] = "timed region, every class bracketed"
-                else:
-                    r["per_class_source"] = f"last {n_prof} warmup steps, every class bracketed; the timed region brackets {' and '.join(focus)} only"
-                r["per_class_ms_per_step"] = per_class
+                r["measured_in"] = measured_in
+                if args.arch == "halfresnet34":
+                    if per_class is None:
+                        per_class = {k: round(v[0] / args.steps, 4) for k, v in prof.items()}
+                        r["per_class_source"] = "timed region, every class bracketed"
+                    else:
+                        r["per_class_source"] = (f"{n_prof} steps with every class bracketed (serial lanes), before the roofline region; that region brackets "
+                                                 f"{' and '.join(focus)} only")
+                    r["per_class_ms_per_step"] = per_class
+                if serial_ms is not None:
+                    r["serial_ms_per_step"] = serial_ms
             out["roofline"] = r
-        if world == 1 and not args.no_cpu_baseline and args.arch == "halfresnet34":
-            out["cpu_baseline"] = cpu_baseline(args.seconds)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.seconds, arch=args.arch, lens=lens)
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.destroy_process_group()

@@ -97,6 +97,15 @@ int xt_features(xt_handle* h, const float* d_wav, int64_t wav_ld, const int32_t*
  * eval output is then the un-normalised linear6 output; the 'aam' branch always normalises (:903). */
 int xt_set_norm_embedding(xt_handle* h, int32_t on);
 
+/* Two-lane forward.  With lanes = 2 (the default; SIDEKIT_AMD_LANES=1 in the environment or xt_set_lanes(h, 1) turns it off) a
+ * HalfResNet34 batch of >= 128 utterances is forwarded as two halves on two HIP streams (the caller's and one the handle owns):
+ * one half's latency-bound kernels run under the other half's convolutions.  Results do not change (every kernel is batch-size
+ * invariant).  lanes = 1 serialises the forward again, for profiles in which one kernel's duration has to mean something.
+ * The reference has no counterpart: its forward is one
+ * stream of cuDNN calls (sidekit/nnet/xvector.py:876-907). */
+int xt_set_lanes(xt_handle* h, int32_t lanes);
+int xt_get_lanes(xt_handle* h);
+
 /* Diagnostics for stage-wise parity tests: keep a device copy of intermediate activations of the
  * next forward ("feats", "stem", "layer1".."layer4", "pooled", "pre_norm", TDNN: "conv1".."conv5").
  * xt_debug_tap copies one to host (raw element type of the trunk: f32, or bf16 for XT_BF16 trunk

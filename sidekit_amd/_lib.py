@@ -41,6 +41,8 @@ SIGNATURES = {
     "xt_forward_features": (ctypes.c_int, [_P, _P, _P, _I32, _I32, _P, _P, _P]),
     "xt_features": (ctypes.c_int, [_P, _P, _I64, _P, _I32, _I64, _P, _P]),
     "xt_set_norm_embedding": (ctypes.c_int, [_P, _I32]),
+    "xt_set_lanes": (ctypes.c_int, [_P, _I32]),
+    "xt_get_lanes": (ctypes.c_int, [_P]),
     "xt_set_profile": (ctypes.c_int, [_P, _I32]),
     "xt_get_profile": (ctypes.c_int, [_P, ctypes.POINTER(_F64), ctypes.POINTER(_I64), _I32]),
     "xt_set_debug": (ctypes.c_int, [_P, _I32]),

@@ -38,8 +38,15 @@ template <> __device__ inline void mma_step<float>(f32x16& acc, const uint4& w, 
 }
 
 enum { LANES_LINEAR = 0, LANES_GRID = 1, LANES_DENSE = 2 };
-template <typename T_, int CIN_, int COUT_, int S_, int WIN_, int TH_, int WM_, int WN_, int MW_, int NW_, int CK_, int TAPS_, int OCC_ = 0, int PD_ = 0, bool SWZ_ = false, int BLK_ = LANES_LINEAR, bool M16_ = false>
+template <typename T_, int CIN_, int COUT_, int S_, int WIN_, int TH_, int WM_, int WN_, int MW_, int NW_, int CK_, int TAPS_, int OCC_ = 0, int PD_ = 0, bool SWZ_ = false, int BLK_ = LANES_LINEAR, bool M16_ = false, bool DIRECT_ = false>
 struct ConvCfg {
+  // DIRECT: the epilogue stores straight from the accumulators (32x32 MFMA layouts).  A lane holds, for its position, four groups of 4
+  // consecutive output channels (8 B of bf16); v_permlane32_swap pairs the groups of lanes r and r + 32 into 16-B pieces of 8
+  // consecutive channels, so a wave's store instruction writes 32 B of each of its 32 positions and two of them complete the lines
+  // (cdna_hip_programming.md T21) -- no transposition through LDS, no barriers, no copy-out pass.  The statistics form then leaves
+  // the border sums of the SE gate to se_pre_kernel, which reads the stored border rows / columns back.
+  static constexpr bool DIRECT = DIRECT_;
+  static_assert(!DIRECT_ || (!M16_), "DIRECT: 32x32 MFMA accumulator layout");
   using T = T_;
   static constexpr int EB = elem<T_>::bytes;
   static constexpr int CIN = CIN_, COUT = COUT_, S = S_, WIN = WIN_, TH = TH_, WM = WM_, WN = WN_, MW = MW_, NW = NW_, CK = CK_;
@@ -106,9 +113,24 @@ struct ConvCfg {
   static constexpr int KRSH = SWSH == 0 ? (GC == 4 ? 2 : (GC == 8 ? 3 : 4)) : (SWSH == 1 ? (GC == 8 ? 2 : 3) : 2);   // log2(GC) - SWSH
   __host__ __device__ static constexpr int swz_key(int row, int col) {
     if (BLK == LANES_GRID) return (((row & (GR - 1)) << KRSH) | ((col >> SWSH) & KCMASK)) & (SWF - 1);
-    if (BLK == LANES_DENSE) return (row * (WIN + 1) + col) & 15;
+    if (BLK == LANES_DENSE) return dense_key((row * (WIN + 1) + col) & 15);
     return (col >> SWSH) & (SWF - 1);
   }
+  // 16x16x32 operand reads (M16): a 16-lane read group is NOT sixteen positions with one chunk -- lanes {0-3, 12-15} carry chunk q of
+  // their positions and lanes {20-27} (tile positions 4-11) chunk q + 1 (the other group: positions 4-11 with chunk q, 0-3 and 12-15 with
+  // q + 1).  Round 2 placed tile positions linearly and measured 41 % (layer 2) and 36 % (layer 4) of all LDS cycles as conflicts, which is
+  // what the address model gives (6.67 / 6.22 cycles per read instead of 4).  Both vanish with a permutation of the tile positions over
+  // the 16 lanes (scripts/lds_conflicts.py):
+  //  GRID 2 x 8 (layer 2): lanes 0-3 and 12-15 own block row 0 (columns 0-3, 4-7), lanes 4-11 block row 1.  Each half group is then eight
+  //    consecutive columns of ONE row: its 4 + 4 positions of either bank-row parity take four different column keys, and the row bit of the
+  //    key separates the two halves -- 16 different slots under every tap shift.
+  //  DENSE (layer 4): lanes 8-11 and 12-15 swap, so positions {0-3, 8-11} / {4-7, 12-15} form the two half groups, and the key of padded
+  //    index x is ((x & 7) << 1) | (x >> 3): the two halves of a group then always differ in bit 0 of the key of index pairs (x, x + 8),
+  //    which the chunk difference of 1 cannot undo.
+  __host__ __device__ static constexpr int dense_key(int x) { return (M16_ && BLK_ == LANES_DENSE) ? (((x & 7) << 1) | (x >> 3)) : x; }
+  __host__ __device__ static constexpr int p16_row(int p) { return GR == 2 ? ((p >= 4 && p < 12) ? 1 : 0) : p / GC; }
+  __host__ __device__ static constexpr int p16_col(int p) { return GR == 2 ? (p < 4 ? p : (p < 12 ? p - 4 : p - 8)) : p % GC; }
+  __host__ __device__ static constexpr int p16_dense(int p) { return p < 8 ? p : (p < 12 ? p + 4 : p - 4); }
   static_assert(!SWZ || (SPP == 4 || SPP == 8 || SPP == 16 || SPP == 32), "swizzled image: 64..512 B per position");
   static constexpr int KS = CB / 32;             // MFMA k-steps (32 B of k) per tap per chunk
   static constexpr int NCH = CIN / CK;           // channel chunks
@@ -128,9 +150,9 @@ struct ConvCfg {
   // M16: tile-linear output position of lane position p (0..15) of 16-position tile t of wave row wm; >= MT: none
   __device__ static inline int lane_pos16(int wm, int t, int p) {
     if constexpr (BLK == LANES_GRID) {
-      return ((2 * wm + t / MW) * GR + p / GC) * WOUT + (t % MW) * GC + p % GC;
+      return ((2 * wm + t / MW) * GR + p16_row(p)) * WOUT + (t % MW) * GC + p16_col(p);
     } else {
-      const int L = t * 16 + p, row = L / (WIN + 1), col = L % (WIN + 1);
+      const int L = t * 16 + p16_dense(p), row = L / (WIN + 1), col = L % (WIN + 1);
       return (col < WIN && row < TH) ? row * WOUT + col : MT;
     }
   }
@@ -202,7 +224,7 @@ void conv3x3_kernel(ConvArgs a) {
   int fixreg = 0;   // GRID without a leading zero position: column -1 of block column 0 is the row's own trailing zero position
   if constexpr (C::BLK == LANES_GRID && C::M16) {
     const int p = lane & 15, q = lane >> 4;
-    const int row0 = p / C::GC, col0 = p % C::GC;    // inside the 16-position block; the block's own offset is an immediate (+ the wave row)
+    const int row0 = C::p16_row(p), col0 = C::p16_col(p);    // inside the 16-position block; the block's own offset is an immediate (+ the wave row)
     const int lanebase = (2 * wm * C::GR + row0) * C::RS + col0 * C::CB;
 #pragma unroll
     for (int t = 0; t < NTR; ++t)
@@ -391,12 +413,12 @@ void conv3x3_kernel(ConvArgs a) {
       // XORed with the k-step; tile and tap offsets are immediates.
       typedef float f32x4v __attribute__((ext_vector_type(4)));
       const int q16 = lane >> 4;
-      int pl = lane & 15;
+      int pl = C::BLK == LANES_DENSE ? C::p16_dense(lane & 15) : (lane & 15);
       if constexpr (C::BLK == LANES_DENSE) asm volatile("" : "+v"(pl));
       auto xaddr16 = [&](int t, int kk) {
         const int tap = kk / C::KS32, sk = kk % C::KS32, dh = tap / 3, dw = tap % 3;
         if constexpr (C::BLK == LANES_DENSE) {
-          const int v = (pl * C::CB + ((((pl + dh * (C::WIN + 1) + dw - 1) & 15) ^ q16) << 4)) ^ (sk << 6);
+          const int v = (pl * C::CB + ((C::dense_key((pl + dh * (C::WIN + 1) + dw - 1) & 15) ^ q16) << 4)) ^ (sk << 6);
           return smem + v + (16 * t + dh * (C::WIN + 1) + dw) * C::CB;   // IMG0 = CB: + 1 position
         } else {
           const int v = tapreg[NTR == 3 ? dh : 0][dw] ^ ((sk << 6) ^ ((C::GR == 2 && (dh & 1)) ? (16 << C::KRSH) : 0));
@@ -504,6 +526,101 @@ void conv3x3_kernel(ConvArgs a) {
   constexpr bool RSC = decltype(form)::value == FORM_RESID_SC;
   const float* gate = (RESID || RSC) ? a.gate : nullptr;
   float* se_part = STATS ? a.se_part : nullptr;
+  if constexpr (C::DIRECT && decltype(form)::value != FORM_RESID_SC) {
+    unsigned char* scut_d = (unsigned char*)a.shortcut;
+#pragma unroll
+    for (int j = 0; j < C::NW; ++j) {
+      const int nbase = (nt0 + j * C::WN + wn) * 32;
+      const float* gate_b = RESID ? gate + (size_t)b * C::COUT : scale;
+      f32x4 sc[4], sh[4], gt[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        sc[g] = *reinterpret_cast<const f32x4*>(scale + nbase + 8 * g + 4 * h);
+        sh[g] = *reinterpret_cast<const f32x4*>(shift + nbase + 8 * g + 4 * h);
+        gt[g] = RESID ? *reinterpret_cast<const f32x4*>(gate_b + nbase + 8 * g + 4 * h) : sc[g];
+      }
+      float ssum[STATS ? 16 : 1];
+      if constexpr (STATS) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) ssum[q] = 0.f;
+      }
+      // this lane's two 16-B pieces of position m sit at channel offsets 16 k + 8 h of the wave's 32-channel tile (bf16),
+      // its four 16-B pieces at 8 g + 4 h (f32)
+      constexpr int NP = C::EB == 2 ? 2 : 4;
+      uint4 sreg[RESID ? C::MW : 1][RESID ? NP : 1];
+      auto paddr = [&](int m, int k) { return ((gpos0 + m) * C::COUT + nbase) * C::EB + (C::EB == 2 ? 32 * k + 16 * h : (8 * k + 4 * h) * 4); };
+      if constexpr (RESID) {
+#pragma unroll
+        for (int i = 0; i < C::MW; ++i) {
+          const int m = C::lane_pos(wm, i, r);
+#pragma unroll
+          for (int k = 0; k < NP; ++k) sreg[i][k] = (m < mvalid) ? *reinterpret_cast<const uint4*>(scut_d + paddr(m, k)) : make_uint4(0, 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < C::MW; ++i) {
+        const int m = C::lane_pos(wm, i, r);
+        const bool valid = m < mvalid;
+        float v[4][4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            float x = accv[i][j][4 * g + q] * sc[g][q] + sh[g][q];
+            if constexpr (RESID) x *= gt[g][q];
+            else if (relu) x = relu_nan(x);
+            if constexpr (C::EB == 2) x = round_bf16(x);
+            v[g][q] = x;
+            if constexpr (STATS) ssum[4 * g + q] += valid ? x : 0.f;
+          }
+        if constexpr (C::EB == 2) {
+          uint32_t P[4][2];
+#pragma unroll
+          for (int g = 0; g < 4; ++g) { P[g][0] = pack_bf16x2(v[g][0], v[g][1]); P[g][1] = pack_bf16x2(v[g][2], v[g][3]); }
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            // lanes r and r + 32: (group 2k of the upper lane) <-> (group 2k + 1 of the lower lane)
+            const auto s0 = __builtin_amdgcn_permlane32_swap(P[2 * k][0], P[2 * k + 1][0], false, false);
+            const auto s1 = __builtin_amdgcn_permlane32_swap(P[2 * k][1], P[2 * k + 1][1], false, false);
+            uint4 piece = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+            if constexpr (RESID) {
+              const uint4 sv = sreg[i][k];
+              const uint32_t vv[4] = {piece.x, piece.y, piece.z, piece.w}, ss[4] = {sv.x, sv.y, sv.z, sv.w};
+              uint32_t rr[4];
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                rr[e] = pack_bf16x2(relu_nan(bf16_to_f32(vv[e] & 0xffff) + bf16_to_f32(ss[e] & 0xffff)),
+                                    relu_nan(bf16_to_f32(vv[e] >> 16) + bf16_to_f32(ss[e] >> 16)));
+              piece = make_uint4(rr[0], rr[1], rr[2], rr[3]);
+            }
+            if (valid && !(a.dbg & 1)) *reinterpret_cast<uint4*>(out + paddr(m, k)) = piece;
+          }
+        } else {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            float4 piece = make_float4(v[g][0], v[g][1], v[g][2], v[g][3]);
+            if constexpr (RESID) {
+              const float4 sf = __builtin_bit_cast(float4, sreg[i][g]);
+              piece = make_float4(relu_nan(piece.x + sf.x), relu_nan(piece.y + sf.y), relu_nan(piece.z + sf.z), relu_nan(piece.w + sf.w));
+            }
+            if (valid && !(a.dbg & 1)) *reinterpret_cast<float4*>(out + paddr(m, g)) = piece;
+          }
+        }
+      }
+      if constexpr (STATS) {
+        float* sp = se_part + (((size_t)b * tiles + tile) * C::WM + wm) * C::COUT + nbase;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) ssum[q] = half_sum_upper_row(ssum[q]);
+        if (r == 16) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<float4*>(sp + 4 * h + 8 * g) = make_float4(ssum[4 * g], ssum[4 * g + 1], ssum[4 * g + 2], ssum[4 * g + 3]);
+        }
+      }
+    }
+    if (true) { stamp(4); stamp(5); }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < C::NW; ++j) {
     __syncthreads();  // every wave is done with the halo tile (j == 0) / the previous sub-tile has been copied out
@@ -885,11 +1002,12 @@ using B_X8   = ConvCfg<bf16_t, 128, 128, 1, 20,  8, 1, 4, 5, 1, 128, 9, 3, 4, tr
 using B_X9   = ConvCfg<bf16_t, 256, 256, 1, 10, 17, 1, 4, 6, 1, 128, 9, 2, 0, true, LANES_DENSE>;       // L4, DENSE lane order, 32x32x16 MFMA
 using B_X10  = ConvCfg<bf16_t,  64,  64, 1, 40,  8, 2, 2, 5, 1, 64, 9, 3, 4, true, LANES_GRID>;          // L2, GRID lane order, 32x32x16 MFMA
 using B_X11  = ConvCfg<bf16_t,  32,  32, 1, 80,  8, 4, 1, 5, 1, 32, 9, 0, 0, true, LANES_GRID>;          // L1, GRID lane order, 32x32x16 MFMA
+using B_X12  = ConvCfg<bf16_t,  32,  32, 1, 80,  8, 4, 1, 5, 1, 32, 9, 0, 0, true, LANES_LINEAR, false, true>;   // L1 with the direct-store epilogue
 using F_X0 = ConvCfg<float,  32,  32, 1, 80,  8, 4, 1, 5, 1, 32, 9>;
 using F_X1 = ConvCfg<float,  64,  64, 1, 40,  8, 2, 2, 5, 1, 64, 9>;
 using F_X2 = ConvCfg<float, 128, 128, 1, 20,  8, 1, 4, 5, 1, 128, 9>;
 using F_X3 = ConvCfg<float, 256, 256, 1, 10, 16, 1, 4, 5, 2, 128, 9>;
-using F_X4 = F_X2; using F_X5 = F_X3; using F_X6 = F_X1; using F_X7 = F_X0; using F_X8 = F_X2; using F_X9 = F_X3; using F_X10 = F_X1; using F_X11 = F_X0;
+using F_X4 = F_X2; using F_X5 = F_X3; using F_X6 = F_X1; using F_X7 = F_X0; using F_X8 = F_X2; using F_X9 = F_X3; using F_X10 = F_X1; using F_X11 = F_X0; using F_X12 = F_X0;
 
 using F_L1   = ConvCfg<float,  32,  32, 1, 80,  8, 4, 1, 5, 1, 32, 9, 0, 0, true>;
 using F_L1S  = ConvCfg<float,  32,  32, 1, 80,  8, 4, 1, 5, 1, 32, 1, 0, 0, true>;
@@ -912,7 +1030,7 @@ static void fill_geom(ConvGeom& g) {
 #define SK_CONV_CASES(X) \
   X(CONV_L1, L1) X(CONV_L1S, L1S) X(CONV_L2A, L2A) X(CONV_L2S, L2S) X(CONV_L2, L2) X(CONV_L3A, L3A) \
   X(CONV_L3S, L3S) X(CONV_L3, L3) X(CONV_L4A, L4A) X(CONV_L4S, L4S) X(CONV_L4, L4) \
-  X(11, X0) X(12, X1) X(13, X2) X(14, X3) X(15, X4) X(16, X5) X(17, X6) X(18, X7) X(19, X8) X(20, X9) X(21, X10) X(22, X11)
+  X(11, X0) X(12, X1) X(13, X2) X(14, X3) X(15, X4) X(16, X5) X(17, X6) X(18, X7) X(19, X8) X(20, X9) X(21, X10) X(22, X11) X(23, X12)
 
 int conv_geom(int shape, int dtype, ConvGeom* g) {
   switch (shape) {

@@ -67,6 +67,25 @@ struct DevBuf {
   void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
 };
 
+
+// One lane of the forward: its own activation / statistics workspace and pinned staging ring for per-utterance integers.
+struct Lane {
+  DevBuf ws_S, ws_feat, ws_act[4], ws_se, ws_col, ws_edge, ws_splitk, ws_gate, ws_ctx, ws_rb, ws_h, ws_e, ws_pooled, ws_pre, ws_int;
+  static constexpr int RING = 4;
+  int* ring_host[RING] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ring_ev[RING];
+  bool ring_used[RING] = {false, false, false, false};
+  size_t ring_bytes = 0;
+  int ring_cur = 0;
+  hipStream_t stream = nullptr;        // lane 1 only: the stream its half of the batch runs on
+  hipEvent_t fork = nullptr, join = nullptr;
+};
+
+static int lanes_from_env() {
+  const char* e = getenv("SIDEKIT_AMD_LANES");
+  return (e && atoi(e) == 1) ? 1 : 2;
+}
+
 }  // namespace sk
 
 using namespace sk;
@@ -105,16 +124,14 @@ struct xt_handle {
   struct TdnnLayer { float *w, *bias, *scale, *shift; int cin, cout, k, dil; };
   std::vector<TdnnLayer> tdnn;
 
-  // workspace
+  // workspace: two lanes.  Lane 0 runs on the caller's stream and is sized for the whole batch; lane 1 (own stream, sized for half a
+  // batch) exists only while the two-lane forward is on: a batch of >= LANE_MIN utterances is then forwarded as two halves on two HIP
+  // streams, so that one half's latency-bound kernels (SE gates, pooling, front-end: 0.8 ms of a 6.5-ms step) run under the other
+  // half's convolutions.  Utterances are independent and every kernel is batch-size invariant, so the x-vectors are the same bits.
   std::vector<std::pair<int, int64_t>> reserved;   // (batch, samples) shapes xt_reserve has sized the workspace for: a batch runs when one of them covers it in BOTH dimensions
-  DevBuf ws_S, ws_feat, ws_act[4], ws_se, ws_col, ws_edge, ws_splitk, ws_gate, ws_ctx, ws_rb, ws_h, ws_e, ws_pooled, ws_pre, ws_int;
-  // pinned staging ring for per-utterance integers
-  static constexpr int RING = 4;
-  int* ring_host[RING] = {nullptr, nullptr, nullptr, nullptr};
-  hipEvent_t ring_ev[RING];
-  bool ring_used[RING] = {false, false, false, false};
-  size_t ring_bytes = 0;
-  int ring_cur = 0;
+  Lane lane[2];
+  int lanes = lanes_from_env();                    // 1: serial (profiling: per-kernel durations mean something), 2: two-lane forward
+  static constexpr int LANE_MIN = 128;
   bool norm_embedding = true;
   // per-kernel-class HIP-event profile (xt_set_profile)
   uint32_t profile = 0;   // bit (slot + 1) per bracketed slot; 1 = all
@@ -526,31 +543,31 @@ struct BatchMeta {
 
 // Per-utterance integers travel host -> device through a small ring of pinned staging slots, each
 // guarded by an event, so the call stays asynchronous and the source never goes out of scope.
-static int ring_begin(xt_handle* h) {
-  h->ring_cur = (h->ring_cur + 1) % xt_handle::RING;
-  if (h->ring_used[h->ring_cur]) SK_HIP(hipEventSynchronize(h->ring_ev[h->ring_cur]));
+static int ring_begin(Lane& ln) {
+  ln.ring_cur = (ln.ring_cur + 1) % Lane::RING;
+  if (ln.ring_used[ln.ring_cur]) SK_HIP(hipEventSynchronize(ln.ring_ev[ln.ring_cur]));
   return SK_OK;
 }
-static int push_ints(xt_handle* h, const std::vector<int>& v, size_t slot_off, const int** dptr, hipStream_t st) {
-  int* base = (int*)h->ws_int.p;
-  SK_CHECK((slot_off + v.size()) * 4 <= h->ws_int.bytes, SK_EWORKSPACE, "integer workspace too small");
-  int* stage = h->ring_host[h->ring_cur] + slot_off;
+static int push_ints(Lane& ln, const std::vector<int>& v, size_t slot_off, const int** dptr, hipStream_t st) {
+  int* base = (int*)ln.ws_int.p;
+  SK_CHECK((slot_off + v.size()) * 4 <= ln.ws_int.bytes, SK_EWORKSPACE, "integer workspace too small");
+  int* stage = ln.ring_host[ln.ring_cur] + slot_off;
   memcpy(stage, v.data(), v.size() * 4);
   SK_HIP(hipMemcpyAsync(base + slot_off, stage, v.size() * 4, hipMemcpyHostToDevice, st));
   *dptr = base + slot_off;
   return SK_OK;
 }
-static int ring_end(xt_handle* h, hipStream_t st) {
-  SK_HIP(hipEventRecord(h->ring_ev[h->ring_cur], st));
-  h->ring_used[h->ring_cur] = true;
+static int ring_end(Lane& ln, hipStream_t st) {
+  SK_HIP(hipEventRecord(ln.ring_ev[ln.ring_cur], st));
+  ln.ring_used[ln.ring_cur] = true;
   return SK_OK;
 }
 
-static int frontend_rows(xt_handle* h, const void* d_wav, int pcm16, int64_t wav_ld, const BatchMeta& m, float* d_feat_rows, hipStream_t st) {
+static int frontend_rows(xt_handle* h, Lane& ln, const void* d_wav, int pcm16, int64_t wav_ld, const BatchMeta& m, float* d_feat_rows, hipStream_t st) {
   const FrontCfg& f = h->fc;
   const int M = m.R ? m.R : m.B * m.T;
   const bool mfcc = h->cfg.arch == XT_ARCH_TDNN;
-  float* logmel = mfcc ? (float*)h->ws_act[3].p : d_feat_rows;   // MFCC: the DCT follows
+  float* logmel = mfcc ? (float*)ln.ws_act[3].p : d_feat_rows;   // MFCC: the DCT follows
   GemmArgs p = gemm_args();
   bool have_logmel = false;
   if (!(mfcc && h->mfcc_dft_gemm)) {
@@ -558,9 +575,9 @@ static int frontend_rows(xt_handle* h, const void* d_wav, int pcm16, int64_t wav
     FftArgs fa;
     fa.n_fft = f.n_fft;
     fa.wav = d_wav; fa.pcm16 = pcm16; fa.wav_ld = wav_ld; fa.nsamples = m.d_nsamples; fa.nsamples_uniform = m.nsamples_uniform; fa.window = h->d_window;
-    fa.tw512 = h->d_tw512; fa.tw1024 = h->d_tw1024; fa.P = (float*)h->ws_S.p; fa.ldp = h->nbp; fa.M = M; fa.t_max = m.T; fa.hop = f.hop;
+    fa.tw512 = h->d_tw512; fa.tw1024 = h->d_tw1024; fa.P = (float*)ln.ws_S.p; fa.ldp = h->nbp; fa.M = M; fa.t_max = m.T; fa.hop = f.hop;
     fa.row_b = m.d_row_b; fa.row_t = m.d_row_t; fa.preemph = 0.97f;
-    SK_CHECK((size_t)M * h->nbp * 4 <= h->ws_S.bytes, SK_EWORKSPACE, "spectrum workspace too small (xt_reserve)");
+    SK_CHECK((size_t)M * h->nbp * 4 <= ln.ws_S.bytes, SK_EWORKSPACE, "spectrum workspace too small (xt_reserve)");
     fa.mel_w = nullptr; fa.mel_start = nullptr; fa.mel_len = nullptr; fa.n_mels = 0; fa.logmel = nullptr; fa.ldl = 0;
     if (h->mel_fused && !h->mel_gemm) {  // power spectrum stays in LDS, the kernel writes log-mel rows
       fa.mel_w = h->d_mel_w; fa.mel_start = h->d_mel_start; fa.mel_len = h->d_mel_len; fa.n_mels = f.n_mels;
@@ -569,7 +586,7 @@ static int frontend_rows(xt_handle* h, const void* d_wav, int pcm16, int64_t wav
     }
     { ProfScope ps(h, XT_PROF_FRONTEND, st); SK_TRY(launch_stft_power_fft(fa, st)); }
     // 2) power x mel filterbank, log(. + 1e-6)
-    p.a_mode = A_PLAIN; p.A = h->ws_S.p; p.lda = h->nbp; p.a_rows = M;
+    p.a_mode = A_PLAIN; p.A = ln.ws_S.p; p.lda = h->nbp; p.a_rows = M;
   } else {
     // 1) frames x DFT basis -> [re | im]   (A/B form of the MFCC front-end: n_fft 2048, win 1024)
     SK_CHECK(!pcm16, SK_EARG, "the DFT-GEMM A/B form of the MFCC front-end (SIDEKIT_AMD_MFCC_DFT_GEMM) takes float32 samples only");
@@ -577,11 +594,11 @@ static int frontend_rows(xt_handle* h, const void* d_wav, int pcm16, int64_t wav
     g.a_mode = A_FRAMES; g.A = d_wav; g.wav_ld = wav_ld; g.window = h->d_window; g.nsamples = m.d_nsamples;
     g.nsamples_uniform = m.nsamples_uniform; g.hop = f.hop; g.t_max = m.T; g.row_b = m.d_row_b; g.row_t = m.d_row_t;
     g.preemph = 0.97f;
-    g.W = h->d_basis; g.ldw = f.win; g.C = (float*)h->ws_S.p; g.ldc = 2 * h->nbp; g.M = M; g.N = 2 * h->nbp; g.K = f.win;
-    SK_CHECK((size_t)M * 2 * h->nbp * 4 <= h->ws_S.bytes, SK_EWORKSPACE, "spectrum workspace too small (xt_reserve)");
+    g.W = h->d_basis; g.ldw = f.win; g.C = (float*)ln.ws_S.p; g.ldc = 2 * h->nbp; g.M = M; g.N = 2 * h->nbp; g.K = f.win;
+    SK_CHECK((size_t)M * 2 * h->nbp * 4 <= ln.ws_S.bytes, SK_EWORKSPACE, "spectrum workspace too small (xt_reserve)");
     { ProfScope ps(h, XT_PROF_FRONTEND, st); SK_TRY(launch_gemm(g, st)); }
     // 2) |.|^2 x mel filterbank, log(. + 1e-6)
-    p.a_mode = A_POWER; p.A = h->ws_S.p; p.lda = 2 * h->nbp; p.kc = h->nbp;
+    p.a_mode = A_POWER; p.A = ln.ws_S.p; p.lda = 2 * h->nbp; p.kc = h->nbp;
   }
   if (!have_logmel) {
     p.W = h->d_fbT; p.ldw = h->nbp; p.M = M; p.N = f.n_mels; p.K = h->nbp; p.act = ACT_LOG_EPS;
@@ -600,14 +617,14 @@ static int frontend_rows(xt_handle* h, const void* d_wav, int pcm16, int64_t wav
   return SK_OK;
 }
 
-static int tail(xt_handle* h, int B, float* d_emb, float* d_logits, hipStream_t st) {
+static int tail(xt_handle* h, Lane& ln, int B, float* d_emb, float* d_logits, hipStream_t st) {
   const int E = h->cfg.emb_dim;
-  SK_TRY(tap(h, "pre_norm", h->ws_pre.p, (size_t)B * E * 4, st));
+  SK_TRY(tap(h, "pre_norm", ln.ws_pre.p, (size_t)B * E * 4, st));
   if (!h->norm_embedding && h->cfg.loss == XT_LOSS_CCE) {  // xvector.py:893-898: cce + is_eval returns x as is
-    SK_HIP(hipMemcpyAsync(d_emb, h->ws_pre.p, (size_t)B * E * 4, hipMemcpyDeviceToDevice, st));
+    SK_HIP(hipMemcpyAsync(d_emb, ln.ws_pre.p, (size_t)B * E * 4, hipMemcpyDeviceToDevice, st));
     return SK_OK;
   }
-  SK_TRY(launch_l2norm((const float*)h->ws_pre.p, d_emb, E, B, st));
+  SK_TRY(launch_l2norm((const float*)ln.ws_pre.p, d_emb, E, B, st));
   if (d_logits) {
     SK_CHECK(h->head_wn != nullptr, SK_ESTATE, "logits requested but the model has no cosine head (loss='cce' returns embeddings only)");
     GemmArgs g = gemm_args();
@@ -619,7 +636,7 @@ static int tail(xt_handle* h, int B, float* d_emb, float* d_logits, hipStream_t 
 }
 
 // HalfResNet34 from CMVN'ed features with element strides (sb, sf, st)
-static int half_from_feats(xt_handle* h, const float* feats, long sb, long sf, long stt, const BatchMeta& m, float* d_emb,
+static int half_from_feats(xt_handle* h, Lane& ln, const float* feats, long sb, long sf, long stt, const BatchMeta& m, float* d_emb,
                            float* d_logits, hipStream_t st) {
   const int dt = h->cfg.dtype == XT_BF16 ? DT_BF16 : DT_F32;
   const int EB = dt == DT_BF16 ? 2 : 4;
@@ -627,8 +644,8 @@ static int half_from_feats(xt_handle* h, const float* feats, long sb, long sf, l
   int Hl[4];
   for (int l = 0; l < 4; ++l) Hl[l] = halve(T, l);
   const size_t act_bytes = (size_t)B * T * 80 * 32 * EB;
-  for (int i = 0; i < 4; ++i) SK_CHECK(act_bytes <= h->ws_act[i].bytes, SK_EWORKSPACE, "activation workspace too small: call xt_reserve(%d, >= %d frames)", B, T);
-  void *X = h->ws_act[0].p, *O1 = h->ws_act[1].p, *O2 = h->ws_act[2].p, *SC = h->ws_act[3].p;
+  for (int i = 0; i < 4; ++i) SK_CHECK(act_bytes <= ln.ws_act[i].bytes, SK_EWORKSPACE, "activation workspace too small: call xt_reserve(%d, >= %d frames)", B, T);
+  void *X = ln.ws_act[0].p, *O1 = ln.ws_act[1].p, *O2 = ln.ws_act[2].p, *SC = ln.ws_act[3].p;
   { ProfScope ps(h, XT_PROF_STEM, st); SK_TRY(launch_stem(feats, sb, sf, stt, h->stem_w, h->stem_scale, h->stem_shift, X, dt, m.lens, B, T, st)); }
   SK_TRY(tap(h, "stem", X, act_bytes, st));
   int prev_li = 0;
@@ -643,7 +660,7 @@ static int half_from_feats(xt_handle* h, const float* feats, long sb, long sf, l
     a.lens = m.lens; a.B = B; a.zeros = h->d_zeros;
     // conv1 + bn1 + relu -> O1, leaving the sums the block's SE gate is derived from
     a.in = X; a.wpack = b.c1.wpack; a.scale = b.c1.scale; a.shift = b.c1.shift; a.out = O1;
-    a.se_part = (float*)h->ws_se.p; a.col_part = (float*)h->ws_col.p; a.edge = (float*)h->ws_edge.p;
+    a.se_part = (float*)ln.ws_se.p; a.col_part = (float*)ln.ws_col.p; a.edge = (float*)ln.ws_edge.p;
     a.halvings_in = lin; a.Hin = Hl[lin]; a.Hout = Hl[li]; a.relu = 1;
     // shortcut rides on conv1's centre tap where that costs no occupancy (the stride-2 shapes already run one workgroup per CU)
     // first block of a layer: by default conv2's epilogue evaluates the 1x1 shortcut conv itself from the block input
@@ -654,8 +671,8 @@ static int half_from_feats(xt_handle* h, const float* feats, long sb, long sf, l
     if (fuse_sc) { a.sc_wpack = b.sc.wpack; a.sc_scale = b.sc.scale; a.sc_shift = b.sc.shift; a.sc_out = SC; }
     {
       const size_t tiles1 = (size_t)cdiv(Hl[li], b.c1.g.th);
-      SK_CHECK((size_t)B * tiles1 * b.c1.g.wm * b.C * 4 <= h->ws_se.bytes && (size_t)B * tiles1 * 2 * b.C * 4 <= h->ws_col.bytes &&
-               (size_t)B * 6 * b.C * 4 <= h->ws_edge.bytes && (size_t)B * b.C * 4 <= h->ws_gate.bytes, SK_EWORKSPACE,
+      SK_CHECK((size_t)B * tiles1 * b.c1.g.wm * b.C * 4 <= ln.ws_se.bytes && (size_t)B * tiles1 * 2 * b.C * 4 <= ln.ws_col.bytes &&
+               (size_t)B * 6 * b.C * 4 <= ln.ws_edge.bytes && (size_t)B * b.C * 4 <= ln.ws_gate.bytes, SK_EWORKSPACE,
                "SE statistics workspace too small for %d x %d frames (xt_reserve)", B, T);
     }
     { ProfScope ps(h, b.c1.shape, st); SK_TRY(launch_conv(b.c1.shape, dt, a, st)); }
@@ -668,15 +685,15 @@ static int half_from_feats(xt_handle* h, const float* feats, long sb, long sf, l
     }
     {  // SE gate, known before conv2 runs (linearity of the plane mean in O1)
       SeArgs se;
-      se.se_part = (const float*)h->ws_se.p; se.col_part = (const float*)h->ws_col.p; se.edge = (const float*)h->ws_edge.p;
+      se.se_part = (const float*)ln.ws_se.p; se.col_part = (const float*)ln.ws_col.p; se.edge = (const float*)ln.ws_edge.p;
       se.tiles = cdiv(Hl[li], b.c1.g.th); se.wm = b.c1.g.wm; se.th = b.c1.g.th; se.w2t = b.w2t; se.w2t_bf16 = h->cfg.dtype == XT_BF16; se.scale2 = b.c2.scale; se.shift2 = b.c2.shift;
-      se.fc1 = b.se_w1; se.fc2 = b.se_w2; se.gate = (float*)h->ws_gate.p; se.lens = m.lens; se.halvings = li; se.wout = wout; se.C = b.C; se.B = B;
+      se.fc1 = b.se_w1; se.fc2 = b.se_w2; se.gate = (float*)ln.ws_gate.p; se.lens = m.lens; se.halvings = li; se.wout = wout; se.C = b.C; se.B = B;
       ProfScope ps(h, XT_PROF_SE_RES, st);
       SK_TRY(launch_se_pre(se, st));
     }
     // conv2 + bn2, * gate, + shortcut, relu -> O2 (the block output)
     a.in = O1; a.wpack = b.c2.wpack; a.scale = b.c2.scale; a.shift = b.c2.shift; a.out = O2;
-    a.se_part = nullptr; a.col_part = nullptr; a.edge = nullptr; a.gate = (const float*)h->ws_gate.p; a.shortcut = shortcut;
+    a.se_part = nullptr; a.col_part = nullptr; a.edge = nullptr; a.gate = (const float*)ln.ws_gate.p; a.shortcut = shortcut;
     a.halvings_in = li; a.Hin = Hl[li]; a.Hout = Hl[li]; a.relu = 0;
     if (inplace_sc) {
       a.shortcut = nullptr; a.sc_in = X; a.sc_hin = Hl[lin];
@@ -697,44 +714,44 @@ static int half_from_feats(xt_handle* h, const float* feats, long sb, long sf, l
   const int xbf = dt == DT_BF16;
   RowSpan rs{nullptr, H4, m.lens, 3, 0};
   ProfScope ps_pool(h, XT_PROF_POOL_TAIL, st);
-  SK_TRY(launch_mean_std(X, xbf, D, D, rs, (float*)h->ws_ctx.p, B, st));
+  SK_TRY(launch_mean_std(X, xbf, D, D, rs, (float*)ln.ws_ctx.p, B, st));
   GemmArgs c = gemm_args();  // context term of attention.0: W1[:, 2560:] . [mean | std] + bias, once per utterance
-  c.A = h->ws_ctx.p; c.lda = 2 * D; c.a_rows = B; c.W = h->att_w1c; c.ldw = 2 * D; c.C = (float*)h->ws_rb.p; c.ldc = 128;
-  c.M = B; c.N = 128; c.K = 2 * D; c.bias = h->att_b1; c.splitk_ws = (float*)h->ws_splitk.p;
+  c.A = ln.ws_ctx.p; c.lda = 2 * D; c.a_rows = B; c.W = h->att_w1c; c.ldw = 2 * D; c.C = (float*)ln.ws_rb.p; c.ldc = 128;
+  c.M = B; c.N = 128; c.K = 2 * D; c.bias = h->att_b1; c.splitk_ws = (float*)ln.ws_splitk.p;
   SK_TRY(launch_gemm(c, st));
   GemmArgs g1 = gemm_args();  // attention.0 on x + ReLU + BatchNorm1d + tanh
-  g1.A = X; g1.a_bf16 = xbf; g1.lda = D; g1.a_rows = R; g1.W = h->att_w1x; g1.ldw = D; g1.C = (float*)h->ws_h.p; g1.ldc = 128;
-  g1.M = R; g1.N = 128; g1.K = D; g1.rowbias = (const float*)h->ws_rb.p; g1.rows_per_group = H4;
+  g1.A = X; g1.a_bf16 = xbf; g1.lda = D; g1.a_rows = R; g1.W = h->att_w1x; g1.ldw = D; g1.C = (float*)ln.ws_h.p; g1.ldc = 128;
+  g1.M = R; g1.N = 128; g1.K = D; g1.rowbias = (const float*)ln.ws_rb.p; g1.rows_per_group = H4;
   g1.act = ACT_RELU_BN_TANH; g1.scale = h->att_bn_scale; g1.shift = h->att_bn_shift; g1.W_bf16 = h->att_w1x_bf16;
   SK_TRY(launch_gemm(g1, st));
   if (xbf && !getenv("SIDEKIT_AMD_ATT_SEPARATE")) {   // bf16 path: attention.4 + softmax + statistics fused, e never leaves the accumulators
-    SK_TRY(launch_att_fused(X, (const float*)h->ws_h.p, h->att_w2_bf16, h->att_b2, D, D, rs, (float*)h->ws_pooled.p, B, st));
+    SK_TRY(launch_att_fused(X, (const float*)ln.ws_h.p, h->att_w2_bf16, h->att_b2, D, D, rs, (float*)ln.ws_pooled.p, B, st));
   } else {
   GemmArgs g2 = gemm_args();  // attention.4
-  g2.A = h->ws_h.p; g2.lda = 128; g2.a_rows = R; g2.W = h->att_w2; g2.ldw = 128; g2.C = (float*)h->ws_e.p; g2.ldc = D;
+  g2.A = ln.ws_h.p; g2.lda = 128; g2.a_rows = R; g2.W = h->att_w2; g2.ldw = 128; g2.C = (float*)ln.ws_e.p; g2.ldc = D;
   g2.M = R; g2.N = D; g2.K = 128; g2.bias = h->att_b2; g2.W_bf16 = h->att_w2_bf16;
   SK_TRY(launch_gemm(g2, st));
-  SK_TRY(launch_att_stats(X, xbf, (const float*)h->ws_e.p, D, D, rs, (float*)h->ws_pooled.p, B, st));
+  SK_TRY(launch_att_stats(X, xbf, (const float*)ln.ws_e.p, D, D, rs, (float*)ln.ws_pooled.p, B, st));
   }
-  SK_TRY(tap(h, "pooled", h->ws_pooled.p, (size_t)B * 2 * D * 4, st));
+  SK_TRY(tap(h, "pooled", ln.ws_pooled.p, (size_t)B * 2 * D * 4, st));
   GemmArgs e = gemm_args();  // lin_be + bn_be (xvector.py:578-581)
-  e.A = h->ws_pooled.p; e.lda = 2 * D; e.a_rows = B; e.W = h->emb_w; e.ldw = 2 * D; e.C = (float*)h->ws_pre.p;
+  e.A = ln.ws_pooled.p; e.lda = 2 * D; e.a_rows = B; e.W = h->emb_w; e.ldw = 2 * D; e.C = (float*)ln.ws_pre.p;
   e.ldc = h->cfg.emb_dim; e.M = B; e.N = h->cfg.emb_dim; e.K = 2 * D; e.scale = h->emb_scale; e.shift = h->emb_shift;
-  if (h->cfg.emb_dim <= 256) e.splitk_ws = (float*)h->ws_splitk.p;
+  if (h->cfg.emb_dim <= 256) e.splitk_ws = (float*)ln.ws_splitk.p;
   SK_TRY(launch_gemm(e, st));
-  return tail(h, B, d_emb, d_logits, st);
+  return tail(h, ln, B, d_emb, d_logits, st);
 }
 
 // TDNN from CMVN'ed MFCC rows [R][80]
-static int tdnn_from_rows(xt_handle* h, const float* rows, const BatchMeta& m, float* d_emb, float* d_logits, hipStream_t st) {
+static int tdnn_from_rows(xt_handle* h, Lane& ln, const float* rows, const BatchMeta& m, float* d_emb, float* d_logits, hipStream_t st) {
   const int R = m.R;
   const float* in = rows;
   int lda = 80;
-  float* bufs[2] = {(float*)h->ws_act[0].p, (float*)h->ws_act[1].p};
+  float* bufs[2] = {(float*)ln.ws_act[0].p, (float*)ln.ws_act[1].p};
   for (int i = 0; i < 5; ++i) {
     const auto& L = h->tdnn[i];
     float* out = bufs[i & 1];
-    SK_CHECK((size_t)R * L.cout * 4 <= h->ws_act[i & 1].bytes, SK_EWORKSPACE, "TDNN activation workspace too small (xt_reserve)");
+    SK_CHECK((size_t)R * L.cout * 4 <= ln.ws_act[i & 1].bytes, SK_EWORKSPACE, "TDNN activation workspace too small (xt_reserve)");
     GemmArgs g = gemm_args();
     g.A = in; g.lda = lda; g.a_rows = R; g.kc = L.k > 1 ? L.cin : 0; g.dil = L.dil;
     g.W = L.w; g.ldw = (long)L.cin * L.k; g.C = out; g.ldc = L.cout; g.M = R; g.N = L.cout; g.K = L.cin * L.k;
@@ -746,17 +763,17 @@ static int tdnn_from_rows(xt_handle* h, const float* rows, const BatchMeta& m, f
   }
   ProfScope ps_pool(h, XT_PROF_POOL_TAIL, st);
   RowSpan rs{m.d_offsets, 0, m.lens, 0, 14};  // context_size()-1 = 4 + 4 + 6 frames consumed by the valid convs
-  SK_TRY(launch_mean_std(in, 0, 1536, 1536, rs, (float*)h->ws_pooled.p, m.B, st));
-  SK_TRY(tap(h, "pooled", h->ws_pooled.p, (size_t)m.B * 3072 * 4, st));
+  SK_TRY(launch_mean_std(in, 0, 1536, 1536, rs, (float*)ln.ws_pooled.p, m.B, st));
+  SK_TRY(tap(h, "pooled", ln.ws_pooled.p, (size_t)m.B * 3072 * 4, st));
   GemmArgs e = gemm_args();  // linear6 (xvector.py:489-491)
-  e.A = h->ws_pooled.p; e.lda = 3072; e.a_rows = m.B; e.W = h->emb_w; e.ldw = 3072; e.C = (float*)h->ws_pre.p; e.ldc = h->cfg.emb_dim;
+  e.A = ln.ws_pooled.p; e.lda = 3072; e.a_rows = m.B; e.W = h->emb_w; e.ldw = 3072; e.C = (float*)ln.ws_pre.p; e.ldc = h->cfg.emb_dim;
   e.M = m.B; e.N = h->cfg.emb_dim; e.K = 3072; e.bias = h->emb_bias;
-  if (h->cfg.emb_dim <= 256) e.splitk_ws = (float*)h->ws_splitk.p;
+  if (h->cfg.emb_dim <= 256) e.splitk_ws = (float*)ln.ws_splitk.p;
   SK_TRY(launch_gemm(e, st));
-  return tail(h, m.B, d_emb, h->cfg.loss == XT_LOSS_AAM ? d_logits : nullptr, st);
+  return tail(h, ln, m.B, d_emb, h->cfg.loss == XT_LOSS_AAM ? d_logits : nullptr, st);
 }
 
-static int make_meta(xt_handle* h, const int32_t* h_counts, int B, int64_t L_or_T, bool counts_are_samples, BatchMeta& m,
+static int make_meta(xt_handle* h, Lane& ln, const int32_t* h_counts, int B, int64_t L_or_T, bool counts_are_samples, BatchMeta& m,
                      hipStream_t st) {
   const FrontCfg& f = h->fc;
   m.B = B;
@@ -782,15 +799,15 @@ static int make_meta(xt_handle* h, const int32_t* h_counts, int B, int64_t L_or_
   if (ragged)
     for (int b = 0; b < B; ++b) SK_CHECK(frames[b] >= 15, SK_EARG, "utterance %d: %d frames < TDNN context of 15", b, frames[b]);
   size_t off = 0;
-  if (!(uniform && !ragged)) SK_TRY(ring_begin(h));
+  if (!(uniform && !ragged)) SK_TRY(ring_begin(ln));
   if (uniform && !ragged) {
     m.lens = Lens{nullptr, frames[0]};
     m.nsamples_uniform = counts_are_samples ? nsamp[0] : 0;
   } else {
     const int* p;
-    SK_TRY(push_ints(h, frames, off, &p, st)); off += B;
+    SK_TRY(push_ints(ln, frames, off, &p, st)); off += B;
     m.lens = Lens{p, 0};
-    if (counts_are_samples) { SK_TRY(push_ints(h, nsamp, off, &m.d_nsamples, st)); off += B; }
+    if (counts_are_samples) { SK_TRY(push_ints(ln, nsamp, off, &m.d_nsamples, st)); off += B; }
   }
   if (ragged) {
     std::vector<int> offs(B), rb, rt;
@@ -800,11 +817,11 @@ static int make_meta(xt_handle* h, const int32_t* h_counts, int B, int64_t L_or_
     for (int b = 0; b < B; ++b)
       for (int t = 0; t < frames[b]; ++t) { rb[offs[b] + t] = b; rt[offs[b] + t] = t; }
     m.R = R;
-    SK_TRY(push_ints(h, offs, off, &m.d_offsets, st)); off += B;
-    SK_TRY(push_ints(h, rb, off, &m.d_row_b, st)); off += R;
-    SK_TRY(push_ints(h, rt, off, &m.d_row_t, st)); off += R;
+    SK_TRY(push_ints(ln, offs, off, &m.d_offsets, st)); off += B;
+    SK_TRY(push_ints(ln, rb, off, &m.d_row_b, st)); off += R;
+    SK_TRY(push_ints(ln, rt, off, &m.d_row_t, st)); off += R;
   }
-  if (!(uniform && !ragged)) SK_TRY(ring_end(h, st));
+  if (!(uniform && !ragged)) SK_TRY(ring_end(ln, st));
   return SK_OK;
 }
 
@@ -839,14 +856,19 @@ int xt_create(const xt_config* cfg, xt_handle** out) {
 int xt_destroy(xt_handle* h) {
   if (!h) return SK_OK;
   for (void* p : h->dev_allocs) (void)hipFree(p);
-  DevBuf* bufs[] = {&h->ws_S, &h->ws_feat, &h->ws_act[0], &h->ws_act[1], &h->ws_act[2], &h->ws_act[3], &h->ws_se, &h->ws_col, &h->ws_edge, &h->ws_splitk, &h->ws_gate,
-                    &h->ws_ctx, &h->ws_rb, &h->ws_h, &h->ws_e, &h->ws_pooled, &h->ws_pre, &h->ws_int};
-  for (DevBuf* b : bufs) b->release();
+  for (Lane& ln : h->lane) {
+    DevBuf* bufs[] = {&ln.ws_S, &ln.ws_feat, &ln.ws_act[0], &ln.ws_act[1], &ln.ws_act[2], &ln.ws_act[3], &ln.ws_se, &ln.ws_col, &ln.ws_edge, &ln.ws_splitk, &ln.ws_gate,
+                      &ln.ws_ctx, &ln.ws_rb, &ln.ws_h, &ln.ws_e, &ln.ws_pooled, &ln.ws_pre, &ln.ws_int};
+    for (DevBuf* b : bufs) b->release();
+    for (int i = 0; i < Lane::RING; ++i)
+      if (ln.ring_host[i]) { (void)hipHostFree(ln.ring_host[i]); (void)hipEventDestroy(ln.ring_ev[i]); }
+    if (ln.stream) (void)hipStreamDestroy(ln.stream);
+    if (ln.fork) (void)hipEventDestroy(ln.fork);
+    if (ln.join) (void)hipEventDestroy(ln.join);
+  }
   for (auto& kv : h->taps) kv.second.buf.release();
   for (auto& r : h->prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
   for (auto e : h->prof_pool) (void)hipEventDestroy(e);
-  for (int i = 0; i < xt_handle::RING; ++i)
-    if (h->ring_host[i]) { (void)hipHostFree(h->ring_host[i]); (void)hipEventDestroy(h->ring_ev[i]); }
   delete h;
   return SK_OK;
 }
@@ -890,33 +912,31 @@ int xt_finalize(xt_handle* h) {
   return SK_OK;
 }
 
-int xt_reserve(xt_handle* h, int32_t max_batch, int64_t max_samples) {
-  SK_CHECK(h && max_batch > 0 && max_samples > 0, SK_EARG, "xt_reserve: bad arguments");
-  SK_HIP(hipSetDevice(h->device));
+static int reserve_lane(xt_handle* h, Lane& ln, int32_t max_batch, int64_t max_samples) {
   const FrontCfg& f = h->fc;
   const size_t B = (size_t)max_batch;
   const size_t T = 1 + (size_t)(max_samples / f.hop);
   const size_t nbp = (size_t)((f.n_fft / 2 + 1 + 3) / 4 * 4);
   const size_t R = B * T;
-  SK_TRY(h->ws_S.ensure(R * 2 * nbp * 4));
-  SK_TRY(h->ws_feat.ensure(R * f.n_out * 4));
+  SK_TRY(ln.ws_S.ensure(R * 2 * nbp * 4));
+  SK_TRY(ln.ws_feat.ensure(R * f.n_out * 4));
   const size_t int_bytes = (4 * B + 2 * R + 16) * 4;
-  SK_TRY(h->ws_int.ensure(int_bytes));
-  if (int_bytes > h->ring_bytes) {
-    for (int i = 0; i < xt_handle::RING; ++i) {
-      if (h->ring_host[i]) { if (h->ring_used[i]) SK_HIP(hipEventSynchronize(h->ring_ev[i])); SK_HIP(hipHostFree(h->ring_host[i])); }
-      else SK_HIP(hipEventCreateWithFlags(&h->ring_ev[i], hipEventDisableTiming));
-      SK_HIP(hipHostMalloc((void**)&h->ring_host[i], int_bytes, hipHostMallocDefault));
-      h->ring_used[i] = false;
+  SK_TRY(ln.ws_int.ensure(int_bytes));
+  if (int_bytes > ln.ring_bytes) {
+    for (int i = 0; i < Lane::RING; ++i) {
+      if (ln.ring_host[i]) { if (ln.ring_used[i]) SK_HIP(hipEventSynchronize(ln.ring_ev[i])); SK_HIP(hipHostFree(ln.ring_host[i])); }
+      else SK_HIP(hipEventCreateWithFlags(&ln.ring_ev[i], hipEventDisableTiming));
+      SK_HIP(hipHostMalloc((void**)&ln.ring_host[i], int_bytes, hipHostMallocDefault));
+      ln.ring_used[i] = false;
     }
-    h->ring_bytes = int_bytes;
+    ln.ring_bytes = int_bytes;
   }
   const size_t E = (size_t)h->cfg.emb_dim;
-  SK_TRY(h->ws_pre.ensure(B * E * 4));
-  SK_TRY(h->ws_splitk.ensure((size_t)32 * (B < 512 ? B : 512) * 256 * 4));  // split-K partials of the skinny GEMMs (N <= 256)
+  SK_TRY(ln.ws_pre.ensure(B * E * 4));
+  SK_TRY(ln.ws_splitk.ensure((size_t)32 * (B < 512 ? B : 512) * 256 * 4));  // split-K partials of the skinny GEMMs (N <= 256)
   if (h->cfg.arch == XT_ARCH_HALFRESNET34) {
     const size_t EB = h->cfg.dtype == XT_BF16 ? 2 : 4;
-    for (int i = 0; i < 4; ++i) SK_TRY(h->ws_act[i].ensure(R * 80 * 32 * EB));
+    for (int i = 0; i < 4; ++i) SK_TRY(ln.ws_act[i].ensure(R * 80 * 32 * EB));
     // SE statistics of the statistics-form convolutions: [B][row tiles][wave rows][C] totals and [B][row tiles][2][C] column
     // sums, sized from the largest first convolution of a block (short utterances: one 2-KB tile of layer 4 per utterance
     // outgrows a per-frame estimate)
@@ -927,22 +947,42 @@ int xt_reserve(xt_handle* h, int32_t max_batch, int64_t max_samples) {
       se_b = s1 > se_b ? s1 : se_b;
       col_b = s2 > col_b ? s2 : col_b;
     }
-    SK_TRY(h->ws_se.ensure(se_b));
-    SK_TRY(h->ws_col.ensure(col_b));
-    SK_TRY(h->ws_edge.ensure(B * 6 * 256 * 4));
-    SK_TRY(h->ws_gate.ensure(B * 256 * 4));
+    SK_TRY(ln.ws_se.ensure(se_b));
+    SK_TRY(ln.ws_col.ensure(col_b));
+    SK_TRY(ln.ws_edge.ensure(B * 6 * 256 * 4));
+    SK_TRY(ln.ws_gate.ensure(B * 256 * 4));
     const size_t H4 = (size_t)halve((int)T, 3);
-    SK_TRY(h->ws_ctx.ensure(B * 5120 * 4));
-    SK_TRY(h->ws_rb.ensure(B * 128 * 4));
-    SK_TRY(h->ws_h.ensure(B * H4 * 128 * 4));
-    SK_TRY(h->ws_e.ensure(B * H4 * 2560 * 4));
-    SK_TRY(h->ws_pooled.ensure(B * 5120 * 4));
+    SK_TRY(ln.ws_ctx.ensure(B * 5120 * 4));
+    SK_TRY(ln.ws_rb.ensure(B * 128 * 4));
+    SK_TRY(ln.ws_h.ensure(B * H4 * 128 * 4));
+    SK_TRY(ln.ws_e.ensure(B * H4 * 2560 * 4));
+    SK_TRY(ln.ws_pooled.ensure(B * 5120 * 4));
   } else {
-    SK_TRY(h->ws_act[0].ensure(R * 1536 * 4));
-    SK_TRY(h->ws_act[1].ensure(R * 512 * 4));
-    SK_TRY(h->ws_act[3].ensure(R * f.n_mels * 4));
-    SK_TRY(h->ws_pooled.ensure(B * 3072 * 4));
+    SK_TRY(ln.ws_act[0].ensure(R * 1536 * 4));
+    SK_TRY(ln.ws_act[1].ensure(R * 512 * 4));
+    SK_TRY(ln.ws_act[3].ensure(R * f.n_mels * 4));
+    SK_TRY(ln.ws_pooled.ensure(B * 3072 * 4));
   }
+  return SK_OK;
+}
+
+// the second lane takes the smaller half of a split batch
+static int reserve_second_lane(xt_handle* h, int32_t max_batch, int64_t max_samples) {
+  if (h->lanes < 2 || max_batch < xt_handle::LANE_MIN || h->cfg.arch != XT_ARCH_HALFRESNET34) return SK_OK;
+  Lane& l1 = h->lane[1];
+  if (!l1.stream) {
+    SK_HIP(hipStreamCreateWithFlags(&l1.stream, hipStreamNonBlocking));
+    SK_HIP(hipEventCreateWithFlags(&l1.fork, hipEventDisableTiming));
+    SK_HIP(hipEventCreateWithFlags(&l1.join, hipEventDisableTiming));
+  }
+  return reserve_lane(h, l1, max_batch / 2, max_samples);
+}
+
+int xt_reserve(xt_handle* h, int32_t max_batch, int64_t max_samples) {
+  SK_CHECK(h && max_batch > 0 && max_samples > 0, SK_EARG, "xt_reserve: bad arguments");
+  SK_HIP(hipSetDevice(h->device));
+  SK_TRY(reserve_lane(h, h->lane[0], max_batch, max_samples));
+  SK_TRY(reserve_second_lane(h, max_batch, max_samples));
   bool covered = false;
   for (auto& r : h->reserved) covered = covered || (r.first >= max_batch && r.second >= max_samples);
   if (!covered) h->reserved.push_back({max_batch, max_samples});
@@ -962,19 +1002,39 @@ static int check_run(xt_handle* h, int B, int64_t L_samples) {
   return SK_OK;
 }
 
+static int forward_lane(xt_handle* h, Lane& ln, const void* d_wav, int pcm16, int64_t wav_ld, const int32_t* h_nsamples, int32_t B, int64_t L,
+                        float* d_emb, float* d_logits, hipStream_t st) {
+  BatchMeta m;
+  SK_TRY(make_meta(h, ln, h_nsamples, B, L, true, m, st));
+  float* feat = (float*)ln.ws_feat.p;
+  SK_TRY(frontend_rows(h, ln, d_wav, pcm16, wav_ld, m, feat, st));
+  const int M = m.R ? m.R : m.B * m.T;
+  SK_TRY(tap(h, "feats", feat, (size_t)M * h->fc.n_out * 4, st));
+  if (h->cfg.arch == XT_ARCH_HALFRESNET34) return half_from_feats(h, ln, feat, (long)m.T * 80, 1, 80, m, d_emb, d_logits, st);
+  return tdnn_from_rows(h, ln, feat, m, d_emb, d_logits, st);
+}
+
 static int forward_wav(xt_handle* h, const void* d_wav, int pcm16, int64_t wav_ld, const int32_t* h_nsamples, int32_t B, int64_t L,
                        float* d_emb, float* d_logits, void* stream) {
   SK_TRY(check_run(h, B, L));
   SK_CHECK(d_wav && d_emb && wav_ld >= L, SK_EARG, "xt_forward: bad buffers");
   hipStream_t st = (hipStream_t)stream;
-  BatchMeta m;
-  SK_TRY(make_meta(h, h_nsamples, B, L, true, m, st));
-  float* feat = (float*)h->ws_feat.p;
-  SK_TRY(frontend_rows(h, d_wav, pcm16, wav_ld, m, feat, st));
-  const int M = m.R ? m.R : m.B * m.T;
-  SK_TRY(tap(h, "feats", feat, (size_t)M * h->fc.n_out * 4, st));
-  if (h->cfg.arch == XT_ARCH_HALFRESNET34) return half_from_feats(h, feat, (long)m.T * 80, 1, 80, m, d_emb, d_logits, st);
-  return tdnn_from_rows(h, feat, m, d_emb, d_logits, st);
+  Lane& l1 = h->lane[1];
+  const bool split = h->lanes > 1 && !h->debug && B >= xt_handle::LANE_MIN && l1.stream && h->cfg.arch == XT_ARCH_HALFRESNET34;
+  if (!split) return forward_lane(h, h->lane[0], d_wav, pcm16, wav_ld, h_nsamples, B, L, d_emb, d_logits, st);
+  // two lanes: rows [0, B0) on the caller's stream, rows [B0, B) on the handle's second stream; the second lane starts behind
+  // everything queued on the caller's stream so far (its input may still be in flight) and the caller's stream continues only
+  // once both halves are done.
+  const int B0 = B - B / 2, B1 = B / 2;
+  const size_t eb = pcm16 ? 2 : 4;
+  SK_HIP(hipEventRecord(l1.fork, st));
+  SK_HIP(hipStreamWaitEvent(l1.stream, l1.fork, 0));
+  SK_TRY(forward_lane(h, h->lane[0], d_wav, pcm16, wav_ld, h_nsamples, B0, L, d_emb, d_logits, st));
+  SK_TRY(forward_lane(h, l1, (const unsigned char*)d_wav + (size_t)B0 * wav_ld * eb, pcm16, wav_ld, h_nsamples ? h_nsamples + B0 : nullptr, B1, L,
+                      d_emb + (size_t)B0 * h->cfg.emb_dim, d_logits ? d_logits + (size_t)B0 * h->cfg.n_spk : nullptr, l1.stream));
+  SK_HIP(hipEventRecord(l1.join, l1.stream));
+  SK_HIP(hipStreamWaitEvent(st, l1.join, 0));
+  return SK_OK;
 }
 
 int xt_forward(xt_handle* h, const float* d_wav, int64_t wav_ld, const int32_t* h_nsamples, int32_t B, int64_t L, float* d_emb,
@@ -993,16 +1053,17 @@ int xt_forward_features(xt_handle* h, const float* d_feats, const int32_t* h_fra
   SK_CHECK(d_feats && d_emb && T > 0, SK_EARG, "xt_forward_features: bad buffers");
   hipStream_t st = (hipStream_t)stream;
   BatchMeta m;
-  SK_TRY(make_meta(h, h_frames, B, T, false, m, st));
+  Lane& ln = h->lane[0];
+  SK_TRY(make_meta(h, ln, h_frames, B, T, false, m, st));
   if (h->cfg.arch == XT_ARCH_HALFRESNET34) {
     m.T = T;  // rows are addressed through the caller's (B, 80, T) strides
-    return half_from_feats(h, d_feats, (long)80 * T, T, 1, m, d_emb, d_logits, st);
+    return half_from_feats(h, ln, d_feats, (long)80 * T, T, 1, m, d_emb, d_logits, st);
   }
-  float* rows = (float*)h->ws_feat.p;
+  float* rows = (float*)ln.ws_feat.p;
   RowSpan rs{m.d_offsets, 0, m.lens, 0, 0};
   hipLaunchKernelGGL(bft_to_rows_kernel, dim3(B), dim3(256), 0, st, d_feats, rows, 80, T, rs);
   SK_HIP(hipGetLastError());
-  return tdnn_from_rows(h, rows, m, d_emb, d_logits, st);
+  return tdnn_from_rows(h, ln, rows, m, d_emb, d_logits, st);
 }
 
 int xt_features(xt_handle* h, const float* d_wav, int64_t wav_ld, const int32_t* h_nsamples, int32_t B, int64_t L,
@@ -1011,9 +1072,10 @@ int xt_features(xt_handle* h, const float* d_wav, int64_t wav_ld, const int32_t*
   SK_CHECK(d_wav && d_feats_out && wav_ld >= L, SK_EARG, "xt_features: bad buffers");
   hipStream_t st = (hipStream_t)stream;
   BatchMeta m;
-  SK_TRY(make_meta(h, h_nsamples, B, L, true, m, st));
-  float* feat = (float*)h->ws_feat.p;
-  SK_TRY(frontend_rows(h, d_wav, 0, wav_ld, m, feat, st));
+  Lane& ln = h->lane[0];
+  SK_TRY(make_meta(h, ln, h_nsamples, B, L, true, m, st));
+  float* feat = (float*)ln.ws_feat.p;
+  SK_TRY(frontend_rows(h, ln, d_wav, 0, wav_ld, m, feat, st));
   const int T = 1 + (int)(L / h->fc.hop);
   RowSpan rs{m.d_offsets, m.T, m.lens, 0, 0};
   hipLaunchKernelGGL(rows_to_bft_kernel, dim3(B), dim3(256), 0, st, feat, d_feats_out, h->fc.n_out, T, rs);
@@ -1026,6 +1088,18 @@ int xt_set_norm_embedding(xt_handle* h, int32_t on) {
   h->norm_embedding = on != 0;
   return SK_OK;
 }
+
+int xt_set_lanes(xt_handle* h, int32_t lanes) {
+  SK_CHECK(h && (lanes == 1 || lanes == 2), SK_EARG, "xt_set_lanes: 1 (serial) or 2");
+  h->lanes = lanes;
+  if (lanes > 1) {   // size the second lane for every shape reserved while the handle was serial
+    SK_HIP(hipSetDevice(h->device));
+    for (auto& r : h->reserved) SK_TRY(reserve_second_lane(h, r.first, r.second));
+  }
+  return SK_OK;
+}
+
+int xt_get_lanes(xt_handle* h) { return h ? h->lanes : 0; }
 
 int xt_set_profile(xt_handle* h, int32_t on) {
   SK_CHECK(h, SK_EARG, "null handle");

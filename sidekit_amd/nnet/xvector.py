@@ -212,6 +212,13 @@ class Xtractor:
         _lib.check(_lib.lib().xt_get_profile(self._handle(dtype), ms, n, 1 if reset else 0))
         return {name: (ms[i], n[i]) for i, name in enumerate(_lib.PROF_NAMES) if n[i]}
 
+    def set_lanes(self, lanes, dtype=None):
+        """1: serial forward, 2: a batch of >= 128 utterances runs as two halves on two HIP streams (``xt_set_lanes``; same bits)."""
+        _lib.check(_lib.lib().xt_set_lanes(self._handle(dtype), int(lanes)))
+
+    def get_lanes(self, dtype=None):
+        return int(_lib.lib().xt_get_lanes(self._handle(dtype)))
+
     def set_debug(self, on, dtype=None):
         _lib.check(_lib.lib().xt_set_debug(self._handle(dtype), 1 if on else 0))
 

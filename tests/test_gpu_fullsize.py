@@ -42,6 +42,31 @@ def test_config2_batch256_4s(model):
     assert rel(emb[[3, 200]], ref) < 1e-4
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "fp32"])
+def test_two_lane_forward_is_bit_identical_to_the_serial_one(model, dtype):
+    """xt_set_lanes: a batch of >= 128 utterances forwarded as two halves on two HIP streams (the product default) against the
+    same batch on one stream -- x-vectors and logits are the same bits, for uniform and for ragged (odd-sized) batches, and a
+    batch below the threshold is not split at all."""
+    g = torch.Generator(device="cuda").manual_seed(5)
+    model.compute_dtype = dtype
+    try:
+        for B, L, ragged in ((256, 64000, False), (131, 40000, True), (64, 30000, False)):
+            wav = 0.1 * torch.randn(B, L, device="cuda", generator=g)
+            lens = torch.randint(L // 3, L + 1, (B,), generator=torch.Generator().manual_seed(B)).tolist() if ragged else None
+            model.set_lanes(2)
+            assert model.get_lanes() == 2
+            lg2, e2 = model(wav, is_eval=True, lengths=lens)
+            lg2b, e2b = model(wav, is_eval=True, lengths=lens)          # steady state: both lanes reuse their workspaces
+            model.set_lanes(1)
+            lg1, e1 = model(wav, is_eval=True, lengths=lens)
+            torch.cuda.synchronize()
+            assert torch.equal(e2, e1) and torch.equal(lg2, lg1) and torch.equal(e2b, e1) and torch.equal(lg2b, lg1), (dtype, B)
+            assert bool(torch.isfinite(e1).all())
+    finally:
+        model.set_lanes(2)
+        model.compute_dtype = None
+
+
 def test_bf16_deviation_does_not_move_the_eer(model):
     """bf16 is judged by EER.  No trained checkpoint or dataset exists offline and a random-weight
     network maps every input to nearly the same direction (cosine 0.995 between any two), so the EER check is
