@@ -348,7 +348,12 @@ def main():
         if use_dist:
             while len(in_flight) >= 2:
                 in_flight.pop(0)[0].wait()
-            in_flight.append((dist.all_gather_into_tensor(gathered[k % 2], emb, async_op=True), emb))
+            work = dist.all_gather_into_tensor(gathered[k % 2], emb, async_op=True)
+            # the next step's kernels are ordered behind the collective on the compute stream (a stream-side wait, the host does
+            # not block): 256 KB per rank is microseconds, and the front-end kernel is not run beside a kernel of another stream
+            # (the two-lane hazard)
+            work.wait()
+            in_flight.append((work, emb))
         return emb
 
     def drain():

@@ -30,7 +30,7 @@ extern "C" {
 #define SK_ESTATE (-5)     /* call order (e.g. forward before finalize) -> RuntimeError          */
 
 enum { XT_ARCH_HALFRESNET34 = 0, XT_ARCH_TDNN = 1 };
-enum { XT_F32 = 0, XT_BF16 = 1, XT_F64 = 2, XT_I64 = 3 };
+enum { XT_F32 = 0, XT_BF16 = 1, XT_F64 = 2, XT_I64 = 3, XT_I16 = 4 };
 enum { XT_LOSS_AAM = 0, XT_LOSS_CCE = 1 };
 
 typedef struct xt_handle xt_handle;
@@ -136,6 +136,14 @@ int sk_bench_conv(int32_t shape, int32_t dtype, int32_t B, int32_t T, int32_t it
                   double* phase_cycles /* [8] mean shader cycles per kernel phase, or NULL */);
 
 const char* xt_last_error(void);
+
+/* Sample-rate conversion of one utterance on the device: `torchaudio.transforms.Resample(orig_freq, new_freq)` as
+ * sidekit/bin/extract_xvectors.py:141-143 applies it to a file whose rate differs from the model's (torchaudio 0.8.2, un-vendored:
+ * windowed-sinc interpolation, lowpass_filter_width 6, roll-off 0.99 -- restated from the published algorithm, parity unpinned).
+ * d_in: n_in samples, XT_F32 or XT_I16 (widened as x / 32768); *n_out = ceil(new * n_in / orig) after reducing the rates by their
+ * gcd; d_out = NULL only queries *n_out. */
+int sk_resample(const void* d_in, int32_t in_dtype, int64_t n_in, int32_t orig_freq, int32_t new_freq, float* d_out,
+                int64_t out_capacity, int64_t* n_out, void* stream);
 
 /* ---- trial scoring ------------------------------------------------------------------------- */
 

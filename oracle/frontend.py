@@ -128,3 +128,32 @@ def mfcc_frontend(x, fb=None, dct=None, window=None, cfg=MFCC_CFG):
     logmel = torch.log(mel + 1e-6)
     mfcc = torch.matmul(logmel.transpose(1, 2), dct.to(spec.dtype)).transpose(1, 2)
     return cmvn(mfcc)
+
+
+def resample_sinc(waveform, orig_freq, new_freq, lowpass_filter_width=6):
+    """``torchaudio.transforms.Resample(orig_freq, new_freq)`` as ``sidekit/bin/extract_xvectors.py:141-143`` applies it.  PARITY
+    UNPINNED: torchaudio is pinned at 0.8.2 (``install.sh:36``) and not vendored; this restates its published algorithm
+    (``torchaudio.compliance.kaldi.resample_waveform`` of that release: windowed-sinc interpolation, roll-off 0.99, evaluated as a
+    strided ``conv1d`` with one filter per output phase) in float64 -- the noise floor of the comparison is then the float32
+    arithmetic of the kernel under test, not this restatement's.  ``waveform``: ``(n,)`` or ``(B, n)``."""
+    import math
+    x = torch.as_tensor(waveform, dtype=torch.float64)
+    squeeze = x.dim() == 1
+    if squeeze:
+        x = x[None]
+    g = math.gcd(int(orig_freq), int(new_freq))
+    O, N = int(orig_freq) // g, int(new_freq) // g
+    base = min(O, N) * 0.99
+    width = math.ceil(lowpass_filter_width * O / base)
+    idx = torch.arange(-width, width + O, dtype=torch.float64)
+    kernels = []
+    for i in range(N):
+        t = ((-i / N + idx / O) * base).clamp(-lowpass_filter_width, lowpass_filter_width) * math.pi
+        window = torch.cos(t / lowpass_filter_width / 2) ** 2
+        kernels.append(torch.where(t == 0, torch.ones_like(t), torch.sin(t) / t) * window)
+    kernel = torch.stack(kernels).view(N, 1, -1) * (base / O)
+    n = x.shape[1]
+    padded = torch.nn.functional.pad(x, (width, width + O))
+    out = torch.nn.functional.conv1d(padded[:, None], kernel, stride=O).transpose(1, 2).reshape(x.shape[0], -1)
+    out = out[..., :int(math.ceil(N * n / O))]
+    return out[0] if squeeze else out

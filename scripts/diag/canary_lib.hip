@@ -1,0 +1,22 @@
+// Diagnostic (not product): LDS canary as a tiny shared library for ctypes -- see lds_canary.hip.
+#include <hip/hip_runtime.h>
+__global__ __launch_bounds__(64) void canary_k(unsigned long long* errors, int iters, int words) {
+  extern __shared__ volatile unsigned buf[];
+  const unsigned tag = 0xC0DE0000u ^ (blockIdx.x * 2654435761u);
+  for (int i = threadIdx.x; i < words; i += 64) buf[i] = tag + i;
+  __syncthreads();
+  unsigned long long bad = 0;
+  for (int it = 0; it < iters; ++it) {
+    __builtin_amdgcn_s_sleep(64);
+    for (int i = threadIdx.x; i < words; i += 64) {
+      const unsigned v = buf[i];
+      if (v != tag + i) { ++bad; buf[i] = tag + i; }
+    }
+    __syncthreads();
+  }
+  if (bad) atomicAdd(errors, bad);
+}
+extern "C" int canary_launch(void* stream, unsigned long long* d_err, int blocks, int iters, int lds_bytes) {
+  hipLaunchKernelGGL(canary_k, dim3(blocks), dim3(64), lds_bytes, (hipStream_t)stream, d_err, iters, lds_bytes / 4);
+  return (int)hipGetLastError();
+}

@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libsidekit_amd.so")
 
 SK_OK, SK_EARG, SK_ESHAPE, SK_EHIP, SK_EWORKSPACE, SK_ESTATE = 0, -1, -2, -3, -4, -5
 XT_ARCH_HALFRESNET34, XT_ARCH_TDNN = 0, 1
-XT_F32, XT_BF16, XT_F64, XT_I64 = 0, 1, 2, 3
+XT_F32, XT_BF16, XT_F64, XT_I64, XT_I16 = 0, 1, 2, 3, 4
 XT_LOSS_AAM, XT_LOSS_CCE = 0, 1
 XT_PROF_SLOTS = 16
 PROF_NAMES = ("conv_L1", "conv_L1S", "conv_L2A", "conv_L2S", "conv_L2", "conv_L3A", "conv_L3S", "conv_L3", "conv_L4A", "conv_L4S",
@@ -48,6 +48,7 @@ SIGNATURES = {
     "xt_set_debug": (ctypes.c_int, [_P, _I32]),
     "xt_debug_tap": (ctypes.c_int, [_P, ctypes.c_char_p, _P, _SZ, ctypes.POINTER(_SZ)]),
     "xt_last_error": (ctypes.c_char_p, []),
+    "sk_resample": (ctypes.c_int, [_P, _I32, _I64, _I32, _I32, _P, _I64, ctypes.POINTER(_I64), _P]),
     "sc_cosine": (ctypes.c_int, [_P, _I32, _P, _I32, _I32, _P, _P]),
     "sc_plda_fast": (ctypes.c_int, [_P, _I32, _P, _I32, _I32, _P, _P, _F64, _F64, _P, _P]),
     "sc_cosine_hist": (ctypes.c_int, [_P, _I32, _P, _I32, _I32, _P, _P, _I32, ctypes.c_float, ctypes.c_float, _I32, _P, _P, _P]),

@@ -70,6 +70,24 @@ def load_model(model_path, device):
     return xtractor.to(device).eval(), archi
 
 
+def precheck(xtractor, entries, sample_rate, workers=8):
+    """Header-only pass over the plain files of ``entries`` (``cmd |`` pipes cannot be probed): raises ``IOError`` for a file that
+    cannot be opened and ``ValueError`` for one too short for the front-end's reflect padding (``n_fft / 2 < samples``, what
+    ``torch.stft(center=True)`` demands in the reference) at the model's rate."""
+    from ..pipeline import probe_wavs
+    plain = [(k, src.strip()) for k, src in entries if not src.strip().endswith("|")]
+    if not plain:
+        return
+    kind, ns, rate, _ = probe_wavs([p for _, p in plain], workers)
+    pre = getattr(xtractor, "preprocessor", None)
+    need = getattr(pre, "n_fft", 0) // 2
+    for (key, path), k, n, r in zip(plain, kind, ns, rate):
+        if k < 0:
+            raise IOError(f"Error processing wav file: {path} ({key}): cannot be opened")
+        if k == 1 and need and -(-int(n) * sample_rate // max(int(r), 1)) <= need:
+            raise ValueError(f"{key}: {int(n)} samples at {int(r)} Hz is too short for the front-end (needs more than {need} samples at {sample_rate} Hz)")
+
+
 @torch.no_grad()
 def main(xtractor, wav_scp, out_file, device, sample_rate=16000, out_file_spk="", spk2utt_file="", batch_size=64, dtype="fp32",
          workers=8, window=8):
@@ -82,10 +100,30 @@ def main(xtractor, wav_scp, out_file, device, sample_rate=16000, out_file_spk=""
     rank = dist.get_rank() if dist.is_initialized() else 0
     world = dist.get_world_size() if dist.is_initialized() else 1
     lo, hi = shard_range(len(keys), rank, world)
+    # every plain file of the shard is probed (native header walk, milliseconds per thousand files) BEFORE any GPU work: an unreadable or
+    # too-short file stops the run here, not after hours of extraction -- and under torch.distributed.run not while the other
+    # ranks already sit in the all-gather
+    precheck(xtractor, [(key, ' '.join(utt2wav[key])) for key in keys[lo:hi]], sample_rate, workers)
     # decode threads -> length-sorted batches inside a sliding window -> pinned staging -> copy stream -> forward, all at
     # once (sidekit_amd/pipeline.py); every row is still computed over its own length
     stream = StreamingExtractor(xtractor, batch_size=batch_size, window=window, workers=workers, sample_rate=sample_rate)
-    mine = dict(stream.run((key, ' '.join(utt2wav[key])) for key in keys[lo:hi]))
+    results = stream.run((key, ' '.join(utt2wav[key])) for key in keys[lo:hi])
+    out_ark = os.path.realpath(os.path.join(os.path.dirname(out_file), os.path.splitext(os.path.basename(out_file))[0]))
+    if world == 1:
+        # one process: every x-vector goes to the ark as its batch comes back (the reference writes per utterance, :147), the scp
+        # grows beside it in arrival order (flushed per batch: what was extracted survives an interruption) and is rewritten in
+        # wav.scp order at the end
+        lines = {}
+        with ArkScpWriter(f"{out_ark}.ark", os.path.realpath(out_file)) as writer:
+            for n, (key, vec) in enumerate(results):
+                lines[key] = writer(key, vec)       # (1, E) float matrix per key, what the reference writes
+                if n % batch_size == batch_size - 1:
+                    writer.flush()
+        with open(os.path.realpath(out_file), "w") as f:
+            for key in utt2wav:
+                f.write(lines[key])
+        vecs = None
+    mine = dict(results) if world > 1 else None
     if world > 1:
         dev = torch.device(xtractor.device)
         block = numpy.concatenate([mine[k] for k in keys[lo:hi]]) if hi > lo else numpy.zeros((0, xtractor.embedding_size), dtype=numpy.float32)
@@ -93,12 +131,9 @@ def main(xtractor, wav_scp, out_file, device, sample_rate=16000, out_file_spk=""
         if rank != 0:
             return
         vecs = {k: full[i:i + 1] for i, k in enumerate(keys)}      # contiguous shards in rank order = wav.scp order
-    else:
-        vecs = mine                                                 # (1, E) float matrix per key, what the reference writes (:147)
-    out_ark = os.path.realpath(os.path.join(os.path.dirname(out_file), os.path.splitext(os.path.basename(out_file))[0]))
-    with ArkScpWriter(f"{out_ark}.ark", os.path.realpath(out_file)) as writer:
-        for key in utt2wav:                  # wav.scp order, as the reference
-            writer(key, vecs[key])
+        with ArkScpWriter(f"{out_ark}.ark", os.path.realpath(out_file)) as writer:
+            for key in utt2wav:              # wav.scp order, as the reference
+                writer(key, vecs[key])
     if out_file_spk:                         # speaker means, L2-normalised (:153-173)
         spk2utt = {}
         with open(spk2utt_file) as f:

@@ -512,7 +512,7 @@ void conv3x3_kernel(ConvArgs a) {
   constexpr int NC = C::WN * 32;                // channels of one out sub-tile
   constexpr int OPS = NC * C::EB + 16;          // out-tile position stride in LDS (padded against bank conflicts)
   static_assert(C::MT * OPS <= C::LDS, "out tile must fit the consumed input buffer");
-  __builtin_amdgcn_s_setprio(3);   // memory phases (epilogue, stores, next tile's DMA) ahead of other workgroups' MFMAs
+  if (!(a.dbg & 128)) __builtin_amdgcn_s_setprio(3);   // memory phases (epilogue, stores, next tile's DMA) ahead of other workgroups' MFMAs
   const int mvalid = (hout_b - ho0) * C::WOUT < C::MT ? (hout_b - ho0) * C::WOUT : C::MT;
   const size_t gpos0 = ((size_t)b * a.Hout + ho0) * C::WOUT;
   auto lds_elem = [&](int m, int c) {
@@ -1045,7 +1045,9 @@ int conv_geom(int shape, int dtype, ConvGeom* g) {
   return SK_EARG;
 }
 
-int launch_conv(int shape, int dtype, const ConvArgs& a, hipStream_t st) {
+int launch_conv(int shape, int dtype, const ConvArgs& a_in, hipStream_t st) {
+  ConvArgs a = a_in;
+  { static const int dbg = getenv("SIDEKIT_AMD_CONV_DBG") ? atoi(getenv("SIDEKIT_AMD_CONV_DBG")) : 0; a.dbg |= dbg; }   // diagnostics only
   switch (shape) {
 #define X(id, name) \
   case id: return dtype == DT_BF16 ? launch_cfg<B_##name>(a, st) : launch_cfg<F_##name>(a, st);

@@ -11,6 +11,9 @@
 // log-mel row itself (the power spectrum then never leaves LDS: 211 MB less to write and read back at B=256 x 4 s).
 #include "kernels.h"
 
+#ifndef FFT_ORDER
+#define FFT_ORDER 1
+#endif
 namespace sk {
 
 struct cf { float x, y; };
@@ -34,6 +37,8 @@ __device__ inline void fft8(cf* v) {
 }
 
 __device__ inline int pad(int i) { return i + (i >> 3); }
+// experiment: order this wave's LDS stores before its following LDS loads explicitly
+__device__ inline void lds_order() { if (FFT_ORDER) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 // One utterance's samples: float32, or 16-bit PCM widened in the load as x / 32768 -- exact in f32, the very numbers the
 // reference's soundfile / torchaudio decode hands its model (sidekit/bin/extract_xvectors.py:57-70), so both entry points give
@@ -83,6 +88,7 @@ __global__ __launch_bounds__(FFT_WAVES * 64) void stft_power_fft_kernel(FftArgs 
   fft8(v);
 #pragma unroll
   for (int r = 0; r < 8; ++r) buf[pad(8 * lane + r)] = v[r];
+  lds_order();
   // ---- pass 1 (Ns = 8)
 #pragma unroll
   for (int r = 0; r < 8; ++r) v[r] = buf[pad(lane + 64 * r)];
@@ -97,6 +103,7 @@ __global__ __launch_bounds__(FFT_WAVES * 64) void stft_power_fft_kernel(FftArgs 
 #pragma unroll
     for (int r = 0; r < 8; ++r) buf[pad(j0 + 8 * r)] = v[r];
   }
+  lds_order();
   // ---- pass 2 (Ns = 64)
 #pragma unroll
   for (int r = 0; r < 8; ++r) v[r] = buf[pad(lane + 64 * r)];
@@ -105,6 +112,7 @@ __global__ __launch_bounds__(FFT_WAVES * 64) void stft_power_fft_kernel(FftArgs 
   fft8(v);
 #pragma unroll
   for (int r = 0; r < 8; ++r) buf[pad(lane + 64 * r)] = v[r];
+  lds_order();
   // ---- real-FFT split: X[k] = (Z[k] + conj Z[512-k]) / 2 - i W^k (Z[k] - conj Z[512-k]) / 2,  W = exp(-2 pi i / 1024)
   for (int k = lane; k < a.ldp; k += 64) {
     float pw = 0.f;
@@ -115,12 +123,31 @@ __global__ __launch_bounds__(FFT_WAVES * 64) void stft_power_fft_kernel(FftArgs 
       const cf wd = cmul(reinterpret_cast<const cf*>(a.tw1024)[k], d);
       const float re = 0.5f * (s.x + wd.y), im = 0.5f * (s.y - wd.x);  // s/2 - i*wd/2
       pw = re * re + im * im;
+#ifdef FFT_SELFCHECK
+      {
+        const cf tw = reinterpret_cast<const cf*>(a.tw1024)[k];
+        const float ex = cosf(6.283185307179586f * k / 1024.f), ey = -sinf(6.283185307179586f * k / 1024.f);
+        if (fabsf(tw.x - ex) > 1e-4f || fabsf(tw.y - ey) > 1e-4f)
+          printf("[fft selfcheck C] block %d wave %d k %d: twiddle read (%g, %g), expected (%g, %g)\n", (int)blockIdx.x, wave, k, tw.x, tw.y, ex, ey);
+        const cf z2 = buf[pad(k & 511)];
+        if (z2.x != zk.x || z2.y != zk.y) printf("[fft selfcheck D] block %d wave %d k %d: second LDS read of Z[k] differs\n", (int)blockIdx.x, wave, k);
+      }
+#endif
     }
     if (a.mel_w) pws[wave][k] = pw;
     else prow[k] = pw;
   }
+#ifdef FFT_SELFCHECK
+  {
+    int bad = 0;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) { const cf z = buf[pad(lane + 64 * r)]; bad += (z.x != v[r].x || z.y != v[r].y) ? 1 : 0; }
+    if (bad) printf("[fft selfcheck A] block %d wave %d lane %d: %d of its 8 pass-2 values changed in LDS before the mel phase\n", (int)blockIdx.x, wave, lane, bad);
+  }
+#endif
   if (a.mel_w) {  // each lane finishes filters lane and lane + 64: a dot product over the filter's own run of bins
     for (int k = 513 + lane; k < 520; k += 64) pws[wave][k] = 0.f;   // the 8-wide steps below may read past bin 512
+    lds_order();
     for (int j = lane; j < a.n_mels; j += 64) {
       const int k0 = a.mel_start[j], n = a.mel_len[j];
       float acc = 0.f;
@@ -132,8 +159,25 @@ __global__ __launch_bounds__(FFT_WAVES * 64) void stft_power_fft_kernel(FftArgs 
         for (int q = 0; q < 8; ++q) acc = fmaf(wv[q], pv[q], acc);
       }
       a.logmel[(long)m * a.ldl + j] = logf(acc + 1e-6f);
+#ifdef FFT_SELFCHECK
+      {
+        float acc2 = 0.f;
+        for (int i = 0; i < n; ++i) acc2 = fmaf(a.mel_w[i * a.n_mels + j], pws[wave][k0 + i], acc2);
+        if (fabsf(acc2 - acc) > 1e-3f * fabsf(acc) + 1e-12f) printf("[fft selfcheck E] block %d wave %d mel %d: filter sum %g, recomputed %g\n", (int)blockIdx.x, wave, j, acc, acc2);
+        const float back = a.logmel[(long)m * a.ldl + j];
+        if (back != logf(acc + 1e-6f)) printf("[fft selfcheck F] block %d wave %d mel %d: stored value reads back differently\n", (int)blockIdx.x, wave, j);
+      }
+#endif
     }
   }
+#ifdef FFT_SELFCHECK
+  {
+    int bad = 0;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) { const cf z = buf[pad(lane + 64 * r)]; bad += (z.x != v[r].x || z.y != v[r].y) ? 1 : 0; }
+    if (bad) printf("[fft selfcheck B] block %d wave %d lane %d: %d of its 8 pass-2 values changed in LDS by the end of the kernel\n", (int)blockIdx.x, wave, lane, bad);
+  }
+#endif
 }
 
 // ---- n_fft = 2048, win = 1024 (the MFCC front-end of the TDNN x-vector, preprocessor.py:65-76) ----------------------------

@@ -235,7 +235,18 @@ __global__ __launch_bounds__(HTHREADS) void cosine_hist_kernel(const float* __re
   const long tiles_n = (Nt + HT - 1) / HT, ntiles = (long)((Ne + HT - 1) / HT) * tiles_n;
   const int srow = tid >> 3, sk4 = (tid & 7) * 4;   // 128 rows x 8 chunks per pass, two passes per operand
   const int nk = (D + 31) / 32;
+  auto flush = [&]() {   // LDS counts -> the global 64-bit counters
+    for (int i = tid; i < 2 * HB; i += HTHREADS) {
+      const unsigned c = hist[i];
+      if (c) atomicAdd((i < HB ? hist_tar : hist_non) + (i & (HB - 1)), (unsigned long long)c);
+      hist[i] = 0u;
+    }
+  };
+  int since_flush = 0;
   for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    // a tile adds at most 65 536 counts to one 32-bit LDS bin: flush before 2^15 tiles could wrap it (a few million x a few
+    // million trials per workgroup get there in the central non-target bins)
+    if (++since_flush == (1 << 15)) { __syncthreads(); flush(); since_flush = 0; __syncthreads(); }
     const int m0 = (int)(tile / tiles_n) * HT, n0 = (int)(tile % tiles_n) * HT;
     float4 re[2], rt[2];
     auto fetch = [&](int k0) {
@@ -309,10 +320,7 @@ __global__ __launch_bounds__(HTHREADS) void cosine_hist_kernel(const float* __re
     }
   }
   __syncthreads();
-  for (int i = tid; i < 2 * HB; i += HTHREADS) {
-    const unsigned c = hist[i];
-    if (c) atomicAdd((i < HB ? hist_tar : hist_non) + (i & (HB - 1)), (unsigned long long)c);
-  }
+  flush();
 }
 
 __global__ void cosine_trials_kernel(const float* __restrict__ E, const float* __restrict__ T, int D, const int* __restrict__ ei,
@@ -491,8 +499,12 @@ int sc_cosine_hist(const float* d_E, int32_t Ne, const float* d_T, int32_t Nt, i
   hipStream_t st = (hipStream_t)stream;
   SK_HIP(hipMemsetAsync(d_hist_tar, 0, (size_t)HB * 8, st));
   SK_HIP(hipMemsetAsync(d_hist_non, 0, (size_t)HB * 8, st));
-  int dev = 0, cus = 256;
-  if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  int dev = 0, cus = 256;   // the CU count of the device the stream belongs to (the NULL stream: the current device)
+  hipDevice_t sdev;
+  if (st && hipStreamGetDevice(st, &sdev) == hipSuccess) dev = (int)sdev;
+  else (void)hipGetDevice(&dev);
+  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  if (cus <= 0) cus = 256;
   const long ntiles = (long)cdiv(Ne, HT) * cdiv(Nt, HT);
   const int grid = (int)(ntiles < (long)cus ? ntiles : (long)cus);   // persistent: one workgroup per CU (64 KB of histograms + 74 KB of operand tiles)
   hipLaunchKernelGGL(cosine_hist_kernel, dim3(grid), dim3(HTHREADS), 0, st, d_E, Ne, d_T, Nt, D, d_labels_e, d_labels_t, self_offset, lo,

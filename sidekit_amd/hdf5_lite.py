@@ -15,6 +15,7 @@ compound types, external / virtual storage, filters other than the three above.
 Format reference: "HDF5 File Format Specification Version 2.0" (public HDF Group document), sections II (superblock),
 III.A (B-trees), III.D (local heaps), IV.A (object headers and their messages).
 """
+import os
 import struct
 import zlib
 
@@ -391,7 +392,7 @@ class Writer:
             a = a.astype("int8")
         if a.dtype.kind == "S" and a.dtype.itemsize == 0:
             a = a.astype("S1")
-        node[parts[-1]] = numpy.ascontiguousarray(a)
+        node[parts[-1]] = numpy.require(a, requirements="C")     # ascontiguousarray would turn a 0-d array into shape (1,)
 
     def save(self, name):
         self._out = bytearray(96)                       # superblock (56) + root symbol-table entry (40), filled in last
@@ -401,8 +402,18 @@ class Writer:
         sb += struct.pack("<QQQQ", 0, UNDEF, eof, UNDEF)
         sb += struct.pack("<QQII", 0, root_hdr, 1, 0) + struct.pack("<QQ", btree, heap)
         self._out[:96] = sb
-        with open(name, "wb") as fh:
-            fh.write(bytes(self._out))
+        # written beside the target and moved over it in one step: a crash or an exception while saving never leaves a truncated
+        # file where the previous one was (StatServer.write(mode='a') rewrites a file that holds earlier statistics)
+        tmp = f"{name}.tmp{os.getpid()}"
+        try:
+            with open(tmp, "wb") as fh:
+                fh.write(bytes(self._out))
+                fh.flush()
+                os.fsync(fh.fileno())
+            os.replace(tmp, name)
+        finally:
+            if os.path.exists(tmp):
+                os.remove(tmp)
 
     # ---- pieces ---------------------------------------------------------------------------------
     def _alloc(self, data):
@@ -449,30 +460,83 @@ class Writer:
         hdr = self._object_header([(0x0011, struct.pack("<QQ", btree, heap), 0)])
         return hdr, btree, heap
 
+    CHUNK_BYTES = 1 << 20          # h5py's guess_chunk aims at about this much per chunk
+    CHUNK_K = 32                   # chunk B-tree fan-out (2K = 64 entries per node; the library default, not recorded in the file)
+
+    def _chunk_rows(self, a):
+        """Chunk = `rows` leading-dimension slices x the full trailing extent: about CHUNK_BYTES each, more only when a two-level
+        B-tree (64 x 64 chunks) would not hold the dataset otherwise, and never 4 GiB (the chunk size field is 32 bits)."""
+        row_bytes = max(1, a.dtype.itemsize * int(numpy.prod(a.shape[1:], dtype=numpy.int64)))
+        target = max(self.CHUNK_BYTES, -(-a.nbytes // (4 * self.CHUNK_K * self.CHUNK_K - 64)))
+        rows = max(1, min(a.shape[0], target // row_bytes))
+        if rows * row_bytes >= 1 << 32:
+            raise NotImplementedError("one leading-dimension slice of the dataset exceeds HDF5's 4 GiB chunk limit")
+        return rows
+
+    def _chunk_btree(self, entries, rank, end_key):
+        """v1 B-tree (node type 1) over `entries` = [(key offsets, nbytes, address)], leaves of up to 2K chunks, one more level above
+        them when needed.  A node's keys are the first offsets of its children plus one closing key."""
+        keysz = 8 + 8 * (rank + 1)
+        cap = 2 * self.CHUNK_K
+
+        def node(level, items, closing):           # items: [(offsets, nbytes, child address)]
+            body = b"TREE" + struct.pack("<BBHQQ", 1, level, len(items), UNDEF, UNDEF)
+            for offs, nbytes, addr in items:
+                body += struct.pack("<II", nbytes, 0) + struct.pack("<%dQ" % (rank + 1), *(list(offs) + [0])) + struct.pack("<Q", addr)
+            body += struct.pack("<II", 0, 0) + struct.pack("<%dQ" % (rank + 1), *(list(closing) + [0]))
+            body += b"\0" * (24 + (cap + 1) * keysz + cap * 8 - len(body))
+            return self._alloc(body)
+
+        if len(entries) <= cap:
+            return node(0, entries, end_key)
+        if len(entries) > cap * cap:
+            raise NotImplementedError("more chunks than a two-level B-tree holds")
+        groups = [entries[i:i + cap] for i in range(0, len(entries), cap)]
+        leaves = []
+        for gi, g in enumerate(groups):
+            closing = groups[gi + 1][0][0] if gi + 1 < len(groups) else end_key
+            leaves.append((g[0][0], g[0][1], node(0, g, closing)))
+        # sibling pointers of the leaves are left undefined: readers (libhdf5, this module) descend from the root
+        return node(1, leaves, end_key)
+
     def _write_dataset(self, a):
         rank = a.ndim
         space = struct.pack("<BBBBI", 1, rank, 1 if rank else 0, 0, 0) + struct.pack("<%dQ" % rank, *a.shape)
         space += struct.pack("<%dQ" % rank, *([UNDEF] * rank))            # maxshape=(None, ...)
         dtype = _datatype_message(a.dtype)
-        fill = struct.pack("<BBBB", 2, 3 if rank and a.size else 2, 2 if rank and a.size else 0, 0)
-        if rank == 0 or a.size == 0:                                      # scalar / empty: contiguous, no filters
+        if rank == 0:                                                     # scalar: contiguous, no filters
+            fill = struct.pack("<BBBB", 2, 2, 0, 0)
             raw = a.tobytes()
-            addr = self._alloc(raw) if raw else UNDEF
-            layout = struct.pack("<BBQQ", 3, 1, addr, len(raw))
+            layout = struct.pack("<BBQQ", 3, 1, self._alloc(raw), len(raw))
             return self._object_header([(0x0001, space, 0), (0x0003, dtype, 1), (0x0005, fill, 1), (0x0008, layout, 0)])
-        raw = zlib.compress(a.tobytes(), self._level)
-        raw += struct.pack("<I", fletcher32(raw))
-        chunk_addr = self._alloc(raw)
-        keysz = 8 + 8 * (rank + 1)
-        node = b"TREE" + struct.pack("<BBHQQ", 1, 0, 1, UNDEF, UNDEF)
-        node += struct.pack("<II", len(raw), 0) + struct.pack("<%dQ" % (rank + 1), *([0] * (rank + 1))) + struct.pack("<Q", chunk_addr)
-        node += struct.pack("<II", 0, 0) + struct.pack("<%dQ" % (rank + 1), *(list(a.shape) + [0]))   # the key past the last chunk
-        node += b"\0" * (24 + (2 * 32 + 1) * keysz + 2 * 32 * 8 - len(node))                              # default chunk B-tree fan-out (K = 32)
-        btree = self._alloc(node)
-        layout = struct.pack("<BBBQ", 3, 2, rank + 1, btree) + struct.pack("<%dI" % (rank + 1), *(list(a.shape) + [a.dtype.itemsize]))
+        # Extendible (maxshape None) datasets must be chunked for libhdf5 to resize them -- the reference appends to its files in
+        # place (StatServer.write(mode='a'), sidekit/statserver.py:430-489).  An empty dataset gets a chunk shape and no chunk
+        # (B-tree address undefined), a non-empty one ~1-MiB chunks along the leading dimension (one chunk of the full shape used
+        # to make every later append allocate a whole-dataset-sized chunk, and broke at 4 GiB).
+        fill = struct.pack("<BBBB", 2, 3, 2, 0)                           # allocate incrementally, fill value undefined-at-write
         pipe = struct.pack("<BBHI", 1, 2, 0, 0)
         pipe += struct.pack("<HHHH", 1, 0, 1, 1) + struct.pack("<II", self._level, 0)      # deflate (optional), one client value + padding
         pipe += struct.pack("<HHHH", 3, 0, 0, 0)                                            # fletcher32
+        if a.size == 0:
+            cdims = [max(1, min(d, 1024)) if d else 1 for d in a.shape]
+            cdims[0] = max(1, min(1024, self.CHUNK_BYTES // max(1, a.dtype.itemsize * int(numpy.prod(cdims[1:], dtype=numpy.int64)))))
+            btree = UNDEF
+        else:
+            rows = self._chunk_rows(a)
+            cdims = [rows] + list(a.shape[1:])
+            entries = []
+            for r0 in range(0, a.shape[0], rows):
+                block = a[r0:r0 + rows]
+                if block.shape[0] < rows:                                  # edge chunks are stored whole
+                    pad = numpy.zeros([rows] + list(a.shape[1:]), dtype=a.dtype)
+                    pad[:block.shape[0]] = block
+                    block = pad
+                raw = zlib.compress(numpy.ascontiguousarray(block).tobytes(), self._level)
+                raw += struct.pack("<I", fletcher32(raw))
+                entries.append(([r0] + [0] * (rank - 1), len(raw), self._alloc(raw)))
+            end_key = [-(-a.shape[0] // rows) * rows] + [0] * (rank - 1)
+            btree = self._chunk_btree(entries, rank, end_key)
+        layout = struct.pack("<BBBQ", 3, 2, rank + 1, btree) + struct.pack("<%dI" % (rank + 1), *(cdims + [a.dtype.itemsize]))
         return self._object_header([(0x0001, space, 0), (0x0003, dtype, 1), (0x0005, fill, 1), (0x000B, pipe, 0), (0x0008, layout, 0)])
 
 

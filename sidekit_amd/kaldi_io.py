@@ -34,8 +34,15 @@ class ArkScpWriter:
         for dim in a.shape:
             self._ark.write(b"\4" + struct.pack("<i", dim))
         self._ark.write(a.tobytes())
+        line = f"{key} {self.ark_path}:{offset}\n"
         if self._scp:
-            self._scp.write(f"{key} {self.ark_path}:{offset}\n")
+            self._scp.write(line)
+        return line
+
+    def flush(self):
+        self._ark.flush()
+        if self._scp:
+            self._scp.flush()
 
     def close(self):
         self._ark.close()

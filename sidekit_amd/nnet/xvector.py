@@ -336,8 +336,8 @@ def _load_segment(data_root_name, seg_id, file_extension, start_cs, stop_cs, sam
     (torchaudio is not installed)."""
     import scipy.io.wavfile
     sr, x = scipy.io.wavfile.read(f"{data_root_name}/{seg_id}.{file_extension}")
-    if sr != sample_rate:
-        raise ValueError(f"{seg_id}: sample rate {sr} != {sample_rate} (resampling is out of scope)")
+    # xsets.py:434-448: a whole file at another rate is resampled, a start / stop segment of one asserts
+    assert sr == sample_rate or stop_cs is None, f"{seg_id}: sample rate {sr} != {sample_rate} for a start / stop segment"
     if x.ndim > 1:
         x = x[:, 0]
     if x.dtype == numpy.int16:
@@ -345,6 +345,9 @@ def _load_segment(data_root_name, seg_id, file_extension, start_cs, stop_cs, sam
     elif x.dtype == numpy.int32:
         x = x.astype(numpy.float32) / 2147483648.0
     x = numpy.ascontiguousarray(x, dtype=numpy.float32)
+    if sr != sample_rate:
+        from ..resample import resample
+        x = resample(x, sr, sample_rate).cpu().numpy()
     start = 0 if start_cs is None else int(start_cs * 0.01 * sample_rate)
     if stop_cs is None:
         duration = int(x.shape[0] - start)          # the reference keeps the whole file in this branch

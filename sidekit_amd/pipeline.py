@@ -218,12 +218,21 @@ class StreamingExtractor:
         self.copy_stream = torch.cuda.Stream(self.device) if self.cuda else None
         self.stats = {"utterances": 0, "batches": 0, "samples": 0, "padded_samples": 0, "native_reads": 0}
 
+    def _resample(self, sample, rate):
+        """A file at another rate: the GPU resampler (``sk_resample``), result back on the host as float32 for the staging path.
+        Rare by construction (a corpus is normally at the model's rate), so the round trip is not optimised."""
+        if not self.cuda:
+            raise ValueError(f"sample rate {rate} != {self.sample_rate}: resampling runs on the GPU (no CPU fallback)")
+        from .resample import resample
+        self.stats["resampled"] = self.stats.get("resampled", 0) + 1
+        return resample(sample, rate, self.sample_rate, self.device).cpu().numpy()
+
     # ---- decode (whatever is not a canonical PCM16 file) ----------------------------------------------------------------
     def _decode(self, key, source):
         if isinstance(source, str):
             sample, rate = load_entry(source)
-            if rate != self.sample_rate:
-                raise ValueError(f"{key}: sample rate {rate} != {self.sample_rate} (resampling is out of scope; resample in the wav.scp pipe)")
+            if rate != self.sample_rate:       # extract_xvectors.py:141-143: Resample(orig_freq=sr, new_freq=sample_rate), on the device
+                sample = self._resample(sample, rate)
         else:
             if callable(source):                       # a deferred decode (e.g. an IdMap row with start / stop), run on the pool
                 source = source()
@@ -242,9 +251,7 @@ class StreamingExtractor:
         futures = {}
         for j, i in enumerate(plain):
             key, src = chunk[i]
-            if kind[j] == 1:
-                if rate[j] != self.sample_rate:
-                    raise ValueError(f"{key}: sample rate {rate[j]} != {self.sample_rate} (resampling is out of scope; resample in the wav.scp pipe)")
+            if kind[j] == 1 and rate[j] == self.sample_rate:        # any other rate goes through the decode pool, which resamples
                 items[i] = _Item(key, ns[j], path=src.strip(), offset=off[j])
         for i, (key, src) in enumerate(chunk):
             if items[i] is None:

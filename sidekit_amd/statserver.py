@@ -63,8 +63,11 @@ class StatServer:
     def write(self, output_file_name, prefix='', mode='w'):
         """``statserver.py:427-489``: float32 statistics, byte-string identifiers, int32 ``start`` / ``stop`` (-1 = unset), every
         dataset gzip + Fletcher-32 with unlimited rows.  ``mode='a'`` on a file that already holds ``<prefix>`` datasets appends
-        the rows to them (the reference resizes in place; here the file is rewritten -- other groups of the file are kept);
-        ``mode='a'`` with a new prefix adds the six datasets beside what the file holds."""
+        the rows to them (the reference resizes in place; here the file is rewritten -- other groups of the file are kept, and
+        the new file replaces the old one atomically, ``os.replace``, so an interrupted save leaves the stored statistics
+        intact); ``mode='a'`` with a new prefix adds the six datasets beside what the file holds.  One divergence on purpose:
+        with ``prefix=''`` the reference's test ``prefix in f`` (``statserver.py:440``) is never true, so its ``mode='a'`` then
+        tries to CREATE datasets that exist and raises; here ``prefix=''`` appends like any other prefix."""
         assert self.validate(), "Error: wrong StatServer format"
         new = {"modelset": self.modelset.astype('S'), "segset": self.segset.astype('S'), "stat0": self.stat0.astype(numpy.float32),
                "stat1": self.stat1.astype(numpy.float32), "start": _h5.bounds_to_file(self.start), "stop": _h5.bounds_to_file(self.stop)}

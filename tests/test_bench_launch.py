@@ -43,3 +43,28 @@ def test_roofline_object_is_stable_for_co_dominant_classes():
     assert a["trunk"] == b["trunk"] and 0.2 < a["trunk"]["frac_time_weighted"] < 1.0
     for r in (a, a["co_dominant"]):
         assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["unit"] in ("GB/s", "TFLOP/s")
+
+
+def test_committed_bench_lines_carry_roofline_and_cpu_baseline():
+    """The bench lines kept under profiles/ for this round (configs[1]: HalfResNet34 bf16 B = 256; configs[3]: TDNN fp32, 512 ragged
+    utterances) are complete: the contract keys, a `roofline` object with a consistent fraction and its provenance, and a
+    `cpu_baseline` with both core counts."""
+    import glob
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r03_bench_line*.json")))
+    assert any("tdnn_config4" in p for p in paths), "profiles/r03_bench_line_tdnn_config4.json is missing"
+    for path in paths:
+        with open(path) as f:
+            d = json.loads(f.read().strip().splitlines()[-1])
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+                  "data", "config", "roofline", "cpu_baseline"):
+            assert k in d, (path, k)
+        assert "workload" in d["config"] and "model" not in d["config"] and d["vs_baseline"] is None
+        assert abs(d["value"] - d["config"]["batch_per_gpu"] * d["n_gpus"] / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+        r = d["roofline"]
+        assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+        assert r["peak"] in (8000.0, 2500.0, 157.3) and "traffic" in r and "traffic_source" in r and r["measured_in"]
+        if "tdnn_config4" in path:
+            assert d["dtype"] == "fp32" and "configs[3]" in d["config"]["workload"] and r["bound"] == "mfma" and r["peak"] == 157.3
+            assert abs(r["achieved"] - r["alg_flops_per_forward"] / (r["tdnn_gemm_ms_per_step"] * 1e-3) / 1e12) < 1e-6 * r["achieved"]
+        c = d["cpu_baseline"]
+        assert c["kind"] == "port" and c["cores"] >= 1 and c["cores_all"] >= c["cores"] and c["value"] > 0 and c["sample"]

@@ -230,3 +230,42 @@ def test_streaming_extractor_is_bit_identical_to_single_calls(gpu, tmp_path):
             assert set(got) == set(ref) and ex.stats["native_reads"] >= 10
             for k in ref:
                 assert numpy.array_equal(got[k], ref[k]), (dtype, bs, k)
+
+
+def test_resample_kernel_and_off_rate_files(gpu, tmp_path):
+    """`sk_resample` against the float64 restatement of torchaudio 0.8.2's Resample (oracle/frontend.py, parity unpinned: torchaudio
+    is not vendored) for up- and down-sampling ratios incl. 44.1 kHz -> 16 kHz (160 phases x 475 taps), float32 and int16 input;
+    then the driver's behaviour (extract_xvectors.py:141-143): an 8 kHz and a 44.1 kHz file among 16 kHz ones are resampled on the
+    device and give the x-vector of the resampled signal."""
+    from oracle import frontend as ofe
+    from sidekit_amd.pipeline import StreamingExtractor
+    from sidekit_amd.resample import resample
+    rs = numpy.random.RandomState(12)
+    for orig, new, n in ((8000, 16000, 4001), (44100, 16000, 30000), (16000, 8000, 5000), (48000, 16000, 9999), (22050, 16000, 777)):
+        x = (0.3 * rs.randn(n)).astype(numpy.float32)
+        want = ofe.resample_sinc(x.astype(numpy.float64), orig, new).numpy()
+        got = resample(x, orig, new).cpu().numpy()
+        assert got.dtype == numpy.float32 and got.shape == want.shape == (-(-new * n // orig),), (orig, new)
+        assert numpy.abs(got - want).max() < 2e-6 * max(1.0, numpy.abs(want).max()) + 2e-6, (orig, new, numpy.abs(got - want).max())
+        pcm = (x * 32768).clip(-32768, 32767).astype(numpy.int16)
+        got16 = resample(pcm, orig, new).cpu().numpy()
+        want16 = ofe.resample_sinc(pcm.astype(numpy.float64) / 32768.0, orig, new).numpy()
+        assert numpy.abs(got16 - want16).max() < 4e-6
+    # a tone stays the same tone: 440 Hz sampled at 8 kHz -> 16 kHz equals the tone sampled at 16 kHz (away from the edges)
+    t8, t16 = numpy.arange(8000) / 8000.0, numpy.arange(16000) / 16000.0
+    up = resample(numpy.sin(2 * numpy.pi * 440 * t8).astype(numpy.float32), 8000, 16000).cpu().numpy()
+    assert numpy.abs(up[200:-200] - numpy.sin(2 * numpy.pi * 440 * t16)[200:-200]).max() < 2e-3
+    m = Xtractor(16, model_archi="halfresnet34", loss="aam", seed=78).to(gpu).eval()
+    entries, ref = [], {}
+    for i, rate in enumerate((16000, 8000, 16000, 44100, 16000)):
+        n = int(rate * 1.3) + 17 * i
+        x = (0.1 * rs.randn(n) * 32768).clip(-32768, 32767).astype(numpy.int16)
+        scipy.io.wavfile.write(tmp_path / f"r{i}.wav", rate, x)
+        entries.append((f"r{i}", str(tmp_path / f"r{i}.wav")))
+        sig = resample(x, rate, 16000) if rate != 16000 else torch.from_numpy(x.astype(numpy.float32) / 32768.0).cuda()
+        ref[f"r{i}"] = m(sig[None], is_eval=True)[1].cpu().numpy()
+    ex = StreamingExtractor(m, batch_size=2, window=2, workers=2)
+    got = dict(ex.run(iter(entries)))
+    assert ex.stats["resampled"] == 2 and set(got) == set(ref)
+    for k in ref:
+        assert numpy.array_equal(got[k], ref[k]), k

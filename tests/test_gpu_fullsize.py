@@ -55,12 +55,14 @@ def test_two_lane_forward_is_bit_identical_to_the_serial_one(model, dtype):
             lens = torch.randint(L // 3, L + 1, (B,), generator=torch.Generator().manual_seed(B)).tolist() if ragged else None
             model.set_lanes(2)
             assert model.get_lanes() == 2
-            lg2, e2 = model(wav, is_eval=True, lengths=lens)
-            lg2b, e2b = model(wav, is_eval=True, lengths=lens)          # steady state: both lanes reuse their workspaces
+            two = [model(wav, is_eval=True, lengths=lens) for _ in range(8 if dtype == "bf16" else 3)]   # steady state: both lanes reuse their workspaces
             model.set_lanes(1)
             lg1, e1 = model(wav, is_eval=True, lengths=lens)
             torch.cuda.synchronize()
-            assert torch.equal(e2, e1) and torch.equal(lg2, lg1) and torch.equal(e2b, e1) and torch.equal(lg2b, lg1), (dtype, B)
+            # every repetition: a kernel that misbehaves beside another lane's kernels does so intermittently (the STFT kernel did,
+            # for a few frames per batch, until both front-ends ran ahead of the fork: DESIGN.md section 6)
+            for lg2, e2 in two:
+                assert torch.equal(e2, e1) and torch.equal(lg2, lg1), (dtype, B, torch.nonzero((e2 != e1).any(dim=1)).flatten().tolist()[:8])
             assert bool(torch.isfinite(e1).all())
     finally:
         model.set_lanes(2)

@@ -142,3 +142,40 @@ def test_native_probe_and_read(tmp_path):
         pipeline.read_pcm16([str(tmp_path / "b.wav")], off[1:2], [5000], [0], numpy.zeros((1, 6000), dtype=numpy.int16))
     with pytest.raises(IOError, match="outside the staging buffer"):       # a row index past the buffer is refused, not written
         pipeline.read_pcm16([str(tmp_path / "b.wav")], off[1:2], ns[1:2], [4], dst)
+
+
+def test_extract_xvectors_main_prechecks_and_writes_incrementally(tmp_path):
+    """`bin.extract_xvectors.main`, one process: the whole shard is probed before the model is touched (an unreadable or too-short
+    file raises up front and nothing has been extracted), x-vectors reach the ark as their batches come back and the scp ends up
+    in wav.scp order."""
+    from types import SimpleNamespace
+    from sidekit_amd.bin import extract_xvectors
+    from sidekit_amd.kaldi_io import read_scp
+    rs = numpy.random.RandomState(5)
+    model = _StubModel()
+    model.embedding_size = 4
+    model.preprocessor = SimpleNamespace(n_fft=1024)
+    expect = {}
+    with open(tmp_path / "wav.scp", "w") as f:
+        for i, n in enumerate((3000, 900, 2100, 1500, 4000, 700, 2600)):
+            x = rs.randint(-20000, 20000, n).astype(numpy.int16)
+            scipy.io.wavfile.write(tmp_path / f"u{i}.wav", 16000, x)
+            f.write(f"utt{i} {tmp_path / f'u{i}.wav'}\n")
+            d = x.astype(numpy.float64) / 32768.0
+            expect[f"utt{i}"] = numpy.array([d.sum(), (d * d).sum(), n, d[0]])
+    extract_xvectors.main(model, str(tmp_path / "wav.scp"), str(tmp_path / "xv.scp"), "cpu", batch_size=2, workers=2, window=2)
+    got = list(read_scp(str(tmp_path / "xv.scp")))
+    assert [k for k, _ in got] == [f"utt{i}" for i in range(7)]                       # wav.scp order although batches are length sorted
+    for k, v in got:
+        assert v.shape == (1, 4) and numpy.allclose(v[0], expect[k], rtol=2e-6, atol=1e-4)
+    # bad corpora are rejected before any forward
+    for bad, exc, what in ((str(tmp_path / "missing.wav"), IOError, "cannot be opened"), (None, ValueError, "too short")):
+        if bad is None:
+            scipy.io.wavfile.write(tmp_path / "short.wav", 16000, numpy.zeros(400, dtype=numpy.int16))
+            bad = str(tmp_path / "short.wav")
+        with open(tmp_path / "bad.scp", "w") as f:
+            f.write(f"utt0 {tmp_path / 'u0.wav'}\nbad {bad}\n")
+        n_calls = len(model.calls)
+        with pytest.raises(exc, match=what):
+            extract_xvectors.main(model, str(tmp_path / "bad.scp"), str(tmp_path / "bad_xv.scp"), "cpu", batch_size=2, workers=2)
+        assert len(model.calls) == n_calls
