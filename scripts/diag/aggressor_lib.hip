@@ -18,12 +18,18 @@ __global__ __launch_bounds__(256) void aggr(float* sink, int iters) {
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         const uint4 x = *reinterpret_cast<const uint4*>(smem + ((off + k * 4096u + (unsigned)it * 272u) % 49152u & ~15u));
-        a.x ^= x.x; b.y ^= x.w;
+        // random, ever-changing operands with sane exponents (bf16 values in [1, 2) with random mantissas and signs)
+        a = make_uint4((x.x & 0x807f807fu) | 0x3f803f80u, (x.y & 0x807f807fu) | 0x3f803f80u, (x.z & 0x807f807fu) | 0x3f803f80u, (x.w & 0x807f807fu) | 0x3f803f80u);
+        b = make_uint4(a.w ^ 0x00150015u, a.x ^ 0x002a002au, a.y ^ 0x00330033u, a.z ^ 0x004c004cu);
       }
     }
     if (MODE & 2) {
 #pragma unroll
-      for (int k = 0; k < 8; ++k) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+      for (int k = 0; k < 8; ++k) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+        a.x ^= 0x00010001u * (unsigned)(k + 1); b.z ^= 0x00020002u * (unsigned)(k + 1);
+      }
+      if ((it & 63) == 63) for (int q = 0; q < 16; ++q) acc[q] *= 1e-3f;   // keep the accumulators finite
     }
     if (MODE & 4) {
 #pragma unroll

@@ -8,6 +8,7 @@ from sidekit_amd import _lib
 _lib.lib()
 can = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "diag", "libcanary.so"))
 can.canary_launch.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+can.canary4_launch.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
 dev = torch.device("cuda", 0)
 m1 = Xtractor(7205, model_archi="halfresnet34", loss="aam", seed=1234).to(dev).eval()
 g = torch.Generator(device="cuda").manual_seed(0)
@@ -25,3 +26,16 @@ for lds in (8192, 16384, 32768):
         m1.forward_features(feats_a)
         torch.cuda.synchronize()
     print(f"stop stage {os.environ.get('SIDEKIT_AMD_STOP_STAGE', '-')} {m1.compute_dtype}: canary LDS {lds} B: words overwritten {int(err.item())}", flush=True)
+
+for lds in (26752, 16384, 40960):
+    err.zero_(); torch.cuda.synchronize()
+    for trial in range(5):
+        can.canary4_launch(ctypes.c_void_p(s2.cuda_stream), ctypes.c_void_p(err.data_ptr()), 256 * 6, 1500, lds)
+        m1.forward_features(feats_a)
+        torch.cuda.synchronize()
+    print(f"stop stage {os.environ.get('SIDEKIT_AMD_STOP_STAGE', '-')} {m1.compute_dtype}: 4-wave canary, LDS {lds} B per workgroup: words that read back wrong {int(err.item())}", flush=True)
+err.zero_(); torch.cuda.synchronize()
+for trial in range(3):
+    can.canary4_launch(ctypes.c_void_p(s2.cuda_stream), ctypes.c_void_p(err.data_ptr()), 256 * 6, 1500, 26752)
+    torch.cuda.synchronize()
+print(f"4-wave canary alone: words that read back wrong {int(err.item())}", flush=True)

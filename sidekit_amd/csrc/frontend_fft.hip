@@ -11,12 +11,10 @@
 // log-mel row itself (the power spectrum then never leaves LDS: 211 MB less to write and read back at B=256 x 4 s).
 #include "kernels.h"
 
-#ifndef FFT_ORDER
-#define FFT_ORDER 1
-#endif
 namespace sk {
 
 struct cf { float x, y; };
+__device__ inline cf ldc(const float* table, int idx);
 __device__ inline cf cadd(cf a, cf b) { return {a.x + b.x, a.y + b.y}; }
 __device__ inline cf csub(cf a, cf b) { return {a.x - b.x, a.y - b.y}; }
 __device__ inline cf cmul(cf a, cf b) { return {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
@@ -37,8 +35,26 @@ __device__ inline void fft8(cf* v) {
 }
 
 __device__ inline int pad(int i) { return i + (i >> 3); }
-// experiment: order this wave's LDS stores before its following LDS loads explicitly
-__device__ inline void lds_order() { if (FFT_ORDER) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// Table / sample reads can be made to bypass the CU's vector L1 (FFT_L1_BYPASS = 1: global_load ... sc1, L2-served) -- a diagnostic
+// switch from the round-3 hunt for the two-lane hazard (it was not the cause, see the Makefile note on this file); plain loads by default.
+#ifndef FFT_L1_BYPASS
+#define FFT_L1_BYPASS 0
+#endif
+__device__ inline cf ldc(const float* table, int idx) {   // complex table entry idx (interleaved re, im)
+  if (FFT_L1_BYPASS) {
+    const unsigned long long u = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(table) + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return cf{__builtin_bit_cast(float, (unsigned)(u & 0xffffffffu)), __builtin_bit_cast(float, (unsigned)(u >> 32))};
+  }
+  return reinterpret_cast<const cf*>(table)[idx];
+}
+__device__ inline float ldf(const float* p) {
+  if (FFT_L1_BYPASS) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return *p;
+}
+__device__ inline int ldi(const int* p) {
+  if (FFT_L1_BYPASS) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return *p;
+}
 
 // One utterance's samples: float32, or 16-bit PCM widened in the load as x / 32768 -- exact in f32, the very numbers the
 // reference's soundfile / torchaudio decode hands its model (sidekit/bin/extract_xvectors.py:57-70), so both entry points give
@@ -46,7 +62,12 @@ __device__ inline void lds_order() { if (FFT_ORDER) asm volatile("s_waitcnt lgkm
 struct SampleRow {
   const void* base; long off; int pcm16;
   __device__ inline float operator[](int i) const {
-    return pcm16 ? (float)reinterpret_cast<const short*>(base)[off + i] * (1.0f / 32768.0f) : reinterpret_cast<const float*>(base)[off + i];
+    if (pcm16) {
+      const short* p = reinterpret_cast<const short*>(base) + off + i;
+      const short v = FFT_L1_BYPASS ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
+      return (float)v * (1.0f / 32768.0f);
+    }
+    return ldf(reinterpret_cast<const float*>(base) + off + i);
   }
 };
 
@@ -76,7 +97,7 @@ __global__ __launch_bounds__(FFT_WAVES * 64) void stft_power_fft_kernel(FftArgs 
     if (i < 0) i = -i;
     if (i >= L) i = 2 * (L - 1) - i;
     const int p = (i == 0) ? 1 : i - 1;
-    return a.window[k] * (w[i] - a.preemph * w[p]);
+    return ldf(a.window + k) * (w[i] - a.preemph * w[p]);
   };
   cf v[8];
   // ---- pass 0 (Ns = 1): inputs straight from the waveform, no twiddles
@@ -88,14 +109,13 @@ __global__ __launch_bounds__(FFT_WAVES * 64) void stft_power_fft_kernel(FftArgs 
   fft8(v);
 #pragma unroll
   for (int r = 0; r < 8; ++r) buf[pad(8 * lane + r)] = v[r];
-  lds_order();
   // ---- pass 1 (Ns = 8)
 #pragma unroll
   for (int r = 0; r < 8; ++r) v[r] = buf[pad(lane + 64 * r)];
   {
     const int k = lane & 7;
 #pragma unroll
-    for (int r = 1; r < 8; ++r) v[r] = cmul(v[r], reinterpret_cast<const cf*>(a.tw512)[k * r * 8]);
+    for (int r = 1; r < 8; ++r) v[r] = cmul(v[r], ldc(a.tw512, k * r * 8));
   }
   fft8(v);
   {
@@ -103,16 +123,14 @@ __global__ __launch_bounds__(FFT_WAVES * 64) void stft_power_fft_kernel(FftArgs 
 #pragma unroll
     for (int r = 0; r < 8; ++r) buf[pad(j0 + 8 * r)] = v[r];
   }
-  lds_order();
   // ---- pass 2 (Ns = 64)
 #pragma unroll
   for (int r = 0; r < 8; ++r) v[r] = buf[pad(lane + 64 * r)];
 #pragma unroll
-  for (int r = 1; r < 8; ++r) v[r] = cmul(v[r], reinterpret_cast<const cf*>(a.tw512)[lane * r]);
+  for (int r = 1; r < 8; ++r) v[r] = cmul(v[r], ldc(a.tw512, lane * r));
   fft8(v);
 #pragma unroll
   for (int r = 0; r < 8; ++r) buf[pad(lane + 64 * r)] = v[r];
-  lds_order();
   // ---- real-FFT split: X[k] = (Z[k] + conj Z[512-k]) / 2 - i W^k (Z[k] - conj Z[512-k]) / 2,  W = exp(-2 pi i / 1024)
   for (int k = lane; k < a.ldp; k += 64) {
     float pw = 0.f;
@@ -120,64 +138,28 @@ __global__ __launch_bounds__(FFT_WAVES * 64) void stft_power_fft_kernel(FftArgs 
       const cf zk = buf[pad(k & 511)], zc0 = buf[pad((512 - k) & 511)];
       const cf zc = {zc0.x, -zc0.y};
       const cf s = cadd(zk, zc), d = csub(zk, zc);
-      const cf wd = cmul(reinterpret_cast<const cf*>(a.tw1024)[k], d);
+      const cf wd = cmul(ldc(a.tw1024, k), d);
       const float re = 0.5f * (s.x + wd.y), im = 0.5f * (s.y - wd.x);  // s/2 - i*wd/2
       pw = re * re + im * im;
-#ifdef FFT_SELFCHECK
-      {
-        const cf tw = reinterpret_cast<const cf*>(a.tw1024)[k];
-        const float ex = cosf(6.283185307179586f * k / 1024.f), ey = -sinf(6.283185307179586f * k / 1024.f);
-        if (fabsf(tw.x - ex) > 1e-4f || fabsf(tw.y - ey) > 1e-4f)
-          printf("[fft selfcheck C] block %d wave %d k %d: twiddle read (%g, %g), expected (%g, %g)\n", (int)blockIdx.x, wave, k, tw.x, tw.y, ex, ey);
-        const cf z2 = buf[pad(k & 511)];
-        if (z2.x != zk.x || z2.y != zk.y) printf("[fft selfcheck D] block %d wave %d k %d: second LDS read of Z[k] differs\n", (int)blockIdx.x, wave, k);
-      }
-#endif
     }
     if (a.mel_w) pws[wave][k] = pw;
     else prow[k] = pw;
   }
-#ifdef FFT_SELFCHECK
-  {
-    int bad = 0;
-#pragma unroll
-    for (int r = 0; r < 8; ++r) { const cf z = buf[pad(lane + 64 * r)]; bad += (z.x != v[r].x || z.y != v[r].y) ? 1 : 0; }
-    if (bad) printf("[fft selfcheck A] block %d wave %d lane %d: %d of its 8 pass-2 values changed in LDS before the mel phase\n", (int)blockIdx.x, wave, lane, bad);
-  }
-#endif
   if (a.mel_w) {  // each lane finishes filters lane and lane + 64: a dot product over the filter's own run of bins
     for (int k = 513 + lane; k < 520; k += 64) pws[wave][k] = 0.f;   // the 8-wide steps below may read past bin 512
-    lds_order();
-    for (int j = lane; j < a.n_mels; j += 64) {
-      const int k0 = a.mel_start[j], n = a.mel_len[j];
+      for (int j = lane; j < a.n_mels; j += 64) {
+      const int k0 = ldi(a.mel_start + j), n = ldi(a.mel_len + j);
       float acc = 0.f;
       for (int i = 0; i < n; i += 8) {   // eight taps per step, all loads in flight together (mel_w is zero-padded to a multiple of 8 rows)
         float wv[8], pv[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) { wv[q] = a.mel_w[(i + q) * a.n_mels + j]; pv[q] = pws[wave][k0 + i + q]; }
+        for (int q = 0; q < 8; ++q) { wv[q] = ldf(a.mel_w + (i + q) * a.n_mels + j); pv[q] = pws[wave][k0 + i + q]; }
 #pragma unroll
         for (int q = 0; q < 8; ++q) acc = fmaf(wv[q], pv[q], acc);
       }
       a.logmel[(long)m * a.ldl + j] = logf(acc + 1e-6f);
-#ifdef FFT_SELFCHECK
-      {
-        float acc2 = 0.f;
-        for (int i = 0; i < n; ++i) acc2 = fmaf(a.mel_w[i * a.n_mels + j], pws[wave][k0 + i], acc2);
-        if (fabsf(acc2 - acc) > 1e-3f * fabsf(acc) + 1e-12f) printf("[fft selfcheck E] block %d wave %d mel %d: filter sum %g, recomputed %g\n", (int)blockIdx.x, wave, j, acc, acc2);
-        const float back = a.logmel[(long)m * a.ldl + j];
-        if (back != logf(acc + 1e-6f)) printf("[fft selfcheck F] block %d wave %d mel %d: stored value reads back differently\n", (int)blockIdx.x, wave, j);
-      }
-#endif
     }
   }
-#ifdef FFT_SELFCHECK
-  {
-    int bad = 0;
-#pragma unroll
-    for (int r = 0; r < 8; ++r) { const cf z = buf[pad(lane + 64 * r)]; bad += (z.x != v[r].x || z.y != v[r].y) ? 1 : 0; }
-    if (bad) printf("[fft selfcheck B] block %d wave %d lane %d: %d of its 8 pass-2 values changed in LDS by the end of the kernel\n", (int)blockIdx.x, wave, lane, bad);
-  }
-#endif
 }
 
 // ---- n_fft = 2048, win = 1024 (the MFCC front-end of the TDNN x-vector, preprocessor.py:65-76) ----------------------------
@@ -212,8 +194,7 @@ __global__ __launch_bounds__(FFT_WAVES * 64) void stft_power_fft2k_kernel(FftArg
   const int m = blockIdx.x * FFT_WAVES + wave;
   if (m >= a.M) return;
   cf* buf = lds + wave * FFT2K_BUF;
-  const cf* twc = reinterpret_cast<const cf*>(a.tw512);    // exp(-2 pi i m / 1024), m = 0..1023
-  const cf* tws = reinterpret_cast<const cf*>(a.tw1024);   // exp(-2 pi i k / 2048), k = 0..1024
+  // a.tw512: exp(-2 pi i m / 1024), m = 0..1023;  a.tw1024: exp(-2 pi i k / 2048), k = 0..1024
   int b, t;
   if (a.row_b) { b = a.row_b[m]; t = a.row_t[m]; } else { b = m / a.t_max; t = m % a.t_max; }
   const int L = a.nsamples ? a.nsamples[b] : a.nsamples_uniform;
@@ -230,7 +211,7 @@ __global__ __launch_bounds__(FFT_WAVES * 64) void stft_power_fft2k_kernel(FftArg
     if (i < 0) i = -i;
     if (i >= L) i = 2 * (L - 1) - i;
     const int p = (i == 0) ? 1 : i - 1;
-    return a.window[k] * (w[i] - a.preemph * w[p]);
+    return ldf(a.window + k) * (w[i] - a.preemph * w[p]);
   };
   cf v[16];
   // ---- pass 0 (radix 8, Ns = 1): butterfly j takes z[j + 128 r]; only r = 2..5 lie inside the window's support
@@ -257,7 +238,7 @@ __global__ __launch_bounds__(FFT_WAVES * 64) void stft_power_fft2k_kernel(FftArg
     for (int u = 0; u < 2; ++u) {
       const int j = lane + 64 * u, k = j & 7;
 #pragma unroll
-      for (int r = 1; r < 8; ++r) x2[u][r] = cmul(x2[u][r], twc[k * r * 16]);
+      for (int r = 1; r < 8; ++r) x2[u][r] = cmul(x2[u][r], ldc(a.tw512, k * r * 16));
       fft8(x2[u]);
     }
 #pragma unroll
@@ -271,7 +252,7 @@ __global__ __launch_bounds__(FFT_WAVES * 64) void stft_power_fft2k_kernel(FftArg
 #pragma unroll
   for (int r = 0; r < 16; ++r) v[r] = buf[pad(lane + 64 * r)];
 #pragma unroll
-  for (int r = 1; r < 16; ++r) v[r] = cmul(v[r], twc[lane * r]);
+  for (int r = 1; r < 16; ++r) v[r] = cmul(v[r], ldc(a.tw512, lane * r));
   fft16(v);
 #pragma unroll
   for (int r = 0; r < 16; ++r) buf[pad(lane + 64 * r)] = v[r];
@@ -282,7 +263,7 @@ __global__ __launch_bounds__(FFT_WAVES * 64) void stft_power_fft2k_kernel(FftArg
       const cf zk = buf[pad(k & 1023)], zc0 = buf[pad((1024 - k) & 1023)];
       const cf zc = {zc0.x, -zc0.y};
       const cf s = cadd(zk, zc), d = csub(zk, zc);
-      const cf wd = cmul(tws[k], d);
+      const cf wd = cmul(ldc(a.tw1024, k), d);
       const float re = 0.5f * (s.x + wd.y), im = 0.5f * (s.y - wd.x);  // s/2 - i*wd/2
       pw = re * re + im * im;
     }
@@ -292,12 +273,12 @@ __global__ __launch_bounds__(FFT_WAVES * 64) void stft_power_fft2k_kernel(FftArg
   if (a.mel_w) {  // each lane finishes filters lane and lane + 64: a dot product over the filter's own run of bins
     for (int k = a.ldp + lane; k < 1032; k += 64) pws[wave][k] = 0.f;   // the 8-wide steps below may read past the last bin
     for (int j = lane; j < a.n_mels; j += 64) {
-      const int k0 = a.mel_start[j], n = a.mel_len[j];
+      const int k0 = ldi(a.mel_start + j), n = ldi(a.mel_len + j);
       float acc = 0.f;
       for (int i = 0; i < n; i += 8) {
         float wv[8], pv[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) { wv[q] = a.mel_w[(i + q) * a.n_mels + j]; pv[q] = pws[wave][k0 + i + q]; }
+        for (int q = 0; q < 8; ++q) { wv[q] = ldf(a.mel_w + (i + q) * a.n_mels + j); pv[q] = pws[wave][k0 + i + q]; }
 #pragma unroll
         for (int q = 0; q < 8; ++q) acc = fmaf(wv[q], pv[q], acc);
       }

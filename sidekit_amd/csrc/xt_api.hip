@@ -1061,25 +1061,27 @@ static int forward_wav(xt_handle* h, const void* d_wav, int pcm16, int64_t wav_l
     SK_TRY(lane_frontend(h, l0, d_wav, pcm16, wav_ld, h_nsamples, B, L, m0, st));
     return lane_trunk(h, l0, m0, d_emb, d_logits, st);
   }
-  // Two lanes: rows [0, B0) and rows [B0, B).  BOTH front-ends run on the caller's stream, one after the other, before the lanes
-  // part: the front-end kernels are not run beside another lane's trunk.  Measured on MI355X (scripts/lane_check*.py,
-  // profiles/r03_two_lane_frontend_hazard.txt): with the STFT kernel of one stream running beside the bf16 layer-1 convolution of
-  // another, a few power-spectrum bins of a few frames per batch came out different from the solo run (5-15 % of the utterances of
-  // a 128-batch, differences up to 7 in a CMVN'ed feature) although nothing in either kernel's LDS or global data was overwritten
-  // and every in-kernel re-read was consistent; torch kernels and synthetic LDS / MFMA co-runners showed nothing.  Unexplained;
-  // the trunk, pooling and tail kernels of two lanes side by side are bit-identical to the serial forward over thousands of
-  // utterances (tests/test_gpu_fullsize.py), so only they overlap.
+  // Two lanes: rows [0, B0) on the caller's stream, rows [B0, B) on the handle's second stream; the second lane starts behind
+  // everything queued on the caller's stream so far (its input may still be in flight) and the caller's stream continues only
+  // once both halves are done.  Round 3 found the first version of this giving a few wrong spectrum bins per batch in the
+  // second lane: the STFT kernel's SLP-formed packed-f32 instructions (v_pk_add_f32 / v_pk_mul_f32 with op_sel / neg modifiers)
+  // misbehave on MI355X beside another stream's dense bf16 MFMAs.  The library is built without them now (csrc/Makefile); the
+  // evidence is under profiles/r03_two_lane_frontend_hazard.txt and tests/test_gpu_fullsize.py repeats the two-lane forward
+  // against the serial one.  SIDEKIT_AMD_LANE_FRONTENDS_FIRST=1 runs both front-ends on the caller's stream ahead of the fork.
   const int B0 = B - B / 2, B1 = B / 2;
   const size_t eb = pcm16 ? 2 : 4;
   BatchMeta m1;
-  SK_TRY(lane_frontend(h, l0, d_wav, pcm16, wav_ld, h_nsamples, B0, L, m0, st));
-  SK_TRY(lane_frontend(h, l1, (const unsigned char*)d_wav + (size_t)B0 * wav_ld * eb, pcm16, wav_ld, h_nsamples ? h_nsamples + B0 : nullptr, B1, L, m1, st));
   static const int diag = getenv("SIDEKIT_AMD_LANE_DIAG") ? atoi(getenv("SIDEKIT_AMD_LANE_DIAG")) : 0;   // diagnostics: 1 = second lane on the caller's stream, 2 = second lane starts after the first has finished
+  static const bool fe_first = getenv("SIDEKIT_AMD_LANE_FRONTENDS_FIRST") != nullptr;
   hipStream_t s1 = (diag & 1) ? st : l1.stream;
+  const void* wav1 = (const unsigned char*)d_wav + (size_t)B0 * wav_ld * eb;
+  const int32_t* ns1 = h_nsamples ? h_nsamples + B0 : nullptr;
+  if (fe_first) SK_TRY(lane_frontend(h, l1, wav1, pcm16, wav_ld, ns1, B1, L, m1, st));
   if (!(diag & 2)) {
     SK_HIP(hipEventRecord(l1.fork, st));
     SK_HIP(hipStreamWaitEvent(s1, l1.fork, 0));
   }
+  SK_TRY(lane_frontend(h, l0, d_wav, pcm16, wav_ld, h_nsamples, B0, L, m0, st));
   SK_TRY(lane_trunk(h, l0, m0, d_emb, d_logits, st));
   if (getenv("SIDEKIT_AMD_LANE_GATE")) {
     if (!h->lane0_done) SK_HIP(hipEventCreateWithFlags(&h->lane0_done, hipEventDisableTiming));
@@ -1089,6 +1091,7 @@ static int forward_wav(xt_handle* h, const void* d_wav, int pcm16, int64_t wav_l
     SK_HIP(hipEventRecord(l1.fork, st));
     SK_HIP(hipStreamWaitEvent(s1, l1.fork, 0));
   }
+  if (!fe_first) SK_TRY(lane_frontend(h, l1, wav1, pcm16, wav_ld, ns1, B1, L, m1, s1));
   SK_TRY(lane_trunk(h, l1, m1, d_emb + (size_t)B0 * h->cfg.emb_dim, d_logits ? d_logits + (size_t)B0 * h->cfg.n_spk : nullptr, s1));
   SK_HIP(hipEventRecord(l1.join, s1));
   SK_HIP(hipStreamWaitEvent(st, l1.join, 0));

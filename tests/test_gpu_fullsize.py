@@ -69,6 +69,33 @@ def test_two_lane_forward_is_bit_identical_to_the_serial_one(model, dtype):
         model.compute_dtype = None
 
 
+def test_front_ends_are_stable_beside_another_streams_bf16_trunk(gpu):
+    """Regression for the round-3 hazard: with SLP-formed packed-f32 instructions (v_pk_add_f32 / v_pk_mul_f32 with op_sel / neg
+    modifiers) the STFT kernels gave a few wrong spectrum bins per batch whenever ANOTHER stream was issuing dense bf16 MFMAs
+    (5-15 % of the utterances of a 128-batch per run: profiles/r03_two_lane_frontend_hazard.txt).  The library is built without
+    them (csrc/Makefile); here both front-ends (log-mel, MFCC) run on a side stream beside a second model's bf16 forward and
+    must reproduce their solo features bit for bit, every time."""
+    m1 = Xtractor(64, model_archi="halfresnet34", loss="aam", seed=1).to(gpu).eval()
+    m2 = Xtractor(64, model_archi="halfresnet34", loss="aam", seed=2).to(gpu).eval()
+    m3 = Xtractor(64, model_archi="xvector", loss="aam", seed=3).to(gpu).eval()
+    g = torch.Generator(device="cuda").manual_seed(1)
+    a = 0.1 * torch.randn(128, 64000, device="cuda", generator=g)
+    b = 0.1 * torch.randn(128, 64000, device="cuda", generator=g)
+    ref2, ref3 = m2.features(b), m3.features(b)
+    m1.compute_dtype = "bf16"
+    m1.set_lanes(1)
+    m1(a, is_eval=True)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    for trial in range(12):
+        m1(a, is_eval=True)                      # main stream: layer-1 .. layer-4 bf16 MFMA kernels
+        with torch.cuda.stream(side):
+            f2, f3 = m2.features(b), m3.features(b)
+        torch.cuda.synchronize()
+        assert torch.equal(f2, ref2), (trial, int((f2 != ref2).any(dim=(1, 2)).sum()))
+        assert torch.equal(f3, ref3), (trial, int((f3 != ref3).any(dim=(1, 2)).sum()))
+
+
 def test_bf16_deviation_does_not_move_the_eer(model):
     """bf16 is judged by EER.  No trained checkpoint or dataset exists offline and a random-weight
     network maps every input to nearly the same direction (cosine 0.995 between any two), so the EER check is
