@@ -1,4 +1,4 @@
-"""Diagnostic: the bf16 trunk truncated at SIDEKIT_AMD_STOP_STAGE beside the front-end of another model on another stream."""
+"""[needs the SIDEKIT_AMD_STOP_STAGE / SIDEKIT_AMD_STOP_LAUNCH hooks that commit afd6222 carried in xt_api.hip; removed afterwards] Diagnostic: the bf16 trunk truncated at SIDEKIT_AMD_STOP_STAGE beside the front-end of another model on another stream."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["SIDEKIT_AMD_LANES"] = "1"

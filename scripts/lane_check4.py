@@ -1,4 +1,4 @@
-"""Diagnostic: LDS canary (scripts/diag/libcanary.so) on a side stream beside the bf16 trunk truncated at SIDEKIT_AMD_STOP_STAGE."""
+"""[needs the SIDEKIT_AMD_STOP_STAGE / SIDEKIT_AMD_STOP_LAUNCH hooks that commit afd6222 carried in xt_api.hip; removed afterwards] Diagnostic: LDS canary (scripts/diag/libcanary.so) on a side stream beside the bf16 trunk truncated at SIDEKIT_AMD_STOP_STAGE."""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["SIDEKIT_AMD_LANES"] = "1"

@@ -1,4 +1,4 @@
-"""Diagnostic: torch kernels as victims on a side stream beside the bf16 trunk truncated after its first convolution."""
+"""[needs the SIDEKIT_AMD_STOP_STAGE / SIDEKIT_AMD_STOP_LAUNCH hooks that commit afd6222 carried in xt_api.hip; removed afterwards] Diagnostic: torch kernels as victims on a side stream beside the bf16 trunk truncated after its first convolution."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["SIDEKIT_AMD_LANES"] = "1"

@@ -1,4 +1,4 @@
-"""Diagnostic: does the truncated bf16 trunk, run ALONE, change memory it does not own (torch tensors allocated around it)?"""
+"""[needs the SIDEKIT_AMD_STOP_STAGE / SIDEKIT_AMD_STOP_LAUNCH hooks that commit afd6222 carried in xt_api.hip; removed afterwards] Diagnostic: does the truncated bf16 trunk, run ALONE, change memory it does not own (torch tensors allocated around it)?"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["SIDEKIT_AMD_LANES"] = "1"

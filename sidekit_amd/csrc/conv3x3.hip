@@ -1003,11 +1003,15 @@ using B_X9   = ConvCfg<bf16_t, 256, 256, 1, 10, 17, 1, 4, 6, 1, 128, 9, 2, 0, tr
 using B_X10  = ConvCfg<bf16_t,  64,  64, 1, 40,  8, 2, 2, 5, 1, 64, 9, 3, 4, true, LANES_GRID>;          // L2, GRID lane order, 32x32x16 MFMA
 using B_X11  = ConvCfg<bf16_t,  32,  32, 1, 80,  8, 4, 1, 5, 1, 32, 9, 0, 0, true, LANES_GRID>;          // L1, GRID lane order, 32x32x16 MFMA
 using B_X12  = ConvCfg<bf16_t,  32,  32, 1, 80,  8, 4, 1, 5, 1, 32, 9, 0, 0, true, LANES_LINEAR, false, true>;   // L1 with the direct-store epilogue
+using B_X13  = ConvCfg<bf16_t, 128, 256, 2, 20,  4, 1, 4, 2, 1, 64, 9, 3, 0, true>;     // L4A in 4-row tiles (24 KB), three workgroups per CU
+using B_X14  = ConvCfg<bf16_t,  64, 128, 2, 40,  2, 1, 4, 2, 1, 64, 9, 3, 0, true>;     // L3A in 2-row tiles (26 KB), three workgroups per CU
+using B_X15  = ConvCfg<bf16_t, 128, 256, 2, 20,  4, 1, 4, 2, 1, 64, 9, 4, 0, true>;     // L4A in 4-row tiles, four workgroups per CU
+using B_X16  = ConvCfg<bf16_t,  64, 128, 2, 40,  2, 1, 4, 2, 1, 64, 9, 4, 0, true>;     // L3A in 2-row tiles, four workgroups per CU
 using F_X0 = ConvCfg<float,  32,  32, 1, 80,  8, 4, 1, 5, 1, 32, 9>;
 using F_X1 = ConvCfg<float,  64,  64, 1, 40,  8, 2, 2, 5, 1, 64, 9>;
 using F_X2 = ConvCfg<float, 128, 128, 1, 20,  8, 1, 4, 5, 1, 128, 9>;
 using F_X3 = ConvCfg<float, 256, 256, 1, 10, 16, 1, 4, 5, 2, 128, 9>;
-using F_X4 = F_X2; using F_X5 = F_X3; using F_X6 = F_X1; using F_X7 = F_X0; using F_X8 = F_X2; using F_X9 = F_X3; using F_X10 = F_X1; using F_X11 = F_X0; using F_X12 = F_X0;
+using F_X4 = F_X2; using F_X5 = F_X3; using F_X6 = F_X1; using F_X7 = F_X0; using F_X8 = F_X2; using F_X9 = F_X3; using F_X10 = F_X1; using F_X11 = F_X0; using F_X12 = F_X0; using F_X13 = F_X3; using F_X14 = F_X2; using F_X15 = F_X3; using F_X16 = F_X2;
 
 using F_L1   = ConvCfg<float,  32,  32, 1, 80,  8, 4, 1, 5, 1, 32, 9, 0, 0, true>;
 using F_L1S  = ConvCfg<float,  32,  32, 1, 80,  8, 4, 1, 5, 1, 32, 1, 0, 0, true>;
@@ -1030,7 +1034,7 @@ static void fill_geom(ConvGeom& g) {
 #define SK_CONV_CASES(X) \
   X(CONV_L1, L1) X(CONV_L1S, L1S) X(CONV_L2A, L2A) X(CONV_L2S, L2S) X(CONV_L2, L2) X(CONV_L3A, L3A) \
   X(CONV_L3S, L3S) X(CONV_L3, L3) X(CONV_L4A, L4A) X(CONV_L4S, L4S) X(CONV_L4, L4) \
-  X(11, X0) X(12, X1) X(13, X2) X(14, X3) X(15, X4) X(16, X5) X(17, X6) X(18, X7) X(19, X8) X(20, X9) X(21, X10) X(22, X11) X(23, X12)
+  X(11, X0) X(12, X1) X(13, X2) X(14, X3) X(15, X4) X(16, X5) X(17, X6) X(18, X7) X(19, X8) X(20, X9) X(21, X10) X(22, X11) X(23, X12) X(24, X13) X(25, X14) X(26, X15) X(27, X16)
 
 int conv_geom(int shape, int dtype, ConvGeom* g) {
   switch (shape) {
@@ -1047,7 +1051,7 @@ int conv_geom(int shape, int dtype, ConvGeom* g) {
 
 int launch_conv(int shape, int dtype, const ConvArgs& a_in, hipStream_t st) {
   ConvArgs a = a_in;
-  { static const int dbg = getenv("SIDEKIT_AMD_CONV_DBG") ? atoi(getenv("SIDEKIT_AMD_CONV_DBG")) : 0; a.dbg |= dbg; }   // diagnostics only
+  { static const int dbg = getenv("SIDEKIT_AMD_CONV_DBG") ? atoi(getenv("SIDEKIT_AMD_CONV_DBG")) : 0; a.dbg |= dbg; }   // diagnostics only: the ablation bits of sk_bench_conv for every convolution of a forward
   switch (shape) {
 #define X(id, name) \
   case id: return dtype == DT_BF16 ? launch_cfg<B_##name>(a, st) : launch_cfg<F_##name>(a, st);

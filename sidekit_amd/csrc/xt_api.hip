@@ -130,7 +130,6 @@ struct xt_handle {
   // half's convolutions.  Utterances are independent and every kernel is batch-size invariant, so the x-vectors are the same bits.
   std::vector<std::pair<int, int64_t>> reserved;   // (batch, samples) shapes xt_reserve has sized the workspace for: a batch runs when one of them covers it in BOTH dimensions
   Lane lane[2];
-  hipEvent_t lane0_done = nullptr;                 // diagnostics (lane_gate)
   int lanes = lanes_from_env();                    // 1: serial (profiling: per-kernel durations mean something), 2: two-lane forward
   static constexpr int LANE_MIN = 128;
   bool norm_embedding = true;
@@ -618,25 +617,6 @@ static int frontend_rows(xt_handle* h, Lane& ln, const void* d_wav, int pcm16, i
   return SK_OK;
 }
 
-// Diagnostics (SIDEKIT_AMD_LANE_GATE=k): the second lane runs beside the first only up to stage boundary k (0 before the front-end,
-// 1 before the stem, 2..5 after the stem / layer 1..3, 6 before pooling, 7 before the embedding GEMM), then waits until the first
-// lane has finished -- bisects a concurrency-dependent difference to the stage that produces it.
-static bool stop_here(int stage) {   // diagnostics (SIDEKIT_AMD_STOP_STAGE=k): the trunk returns at stage boundary k, outputs undefined
-  static const int stop = getenv("SIDEKIT_AMD_STOP_STAGE") ? atoi(getenv("SIDEKIT_AMD_STOP_STAGE")) : -1;
-  return stop == stage;
-}
-
-static bool stop_launch(int n) {   // diagnostics (SIDEKIT_AMD_STOP_LAUNCH=n): the trunk returns after its n-th conv / SE launch
-  static const int stop = getenv("SIDEKIT_AMD_STOP_LAUNCH") ? atoi(getenv("SIDEKIT_AMD_STOP_LAUNCH")) : -1;
-  return stop == n;
-}
-
-static int lane_gate(xt_handle* h, Lane& ln, int stage, hipStream_t st) {
-  static const int gate = getenv("SIDEKIT_AMD_LANE_GATE") ? atoi(getenv("SIDEKIT_AMD_LANE_GATE")) : -1;
-  if (gate == stage && &ln == &h->lane[1] && h->lane0_done) SK_HIP(hipStreamWaitEvent(st, h->lane0_done, 0));
-  return SK_OK;
-}
-
 static int tail(xt_handle* h, Lane& ln, int B, float* d_emb, float* d_logits, hipStream_t st) {
   const int E = h->cfg.emb_dim;
   SK_TRY(tap(h, "pre_norm", ln.ws_pre.p, (size_t)B * E * 4, st));
@@ -666,11 +646,8 @@ static int half_from_feats(xt_handle* h, Lane& ln, const float* feats, long sb, 
   const size_t act_bytes = (size_t)B * T * 80 * 32 * EB;
   for (int i = 0; i < 4; ++i) SK_CHECK(act_bytes <= ln.ws_act[i].bytes, SK_EWORKSPACE, "activation workspace too small: call xt_reserve(%d, >= %d frames)", B, T);
   void *X = ln.ws_act[0].p, *O1 = ln.ws_act[1].p, *O2 = ln.ws_act[2].p, *SC = ln.ws_act[3].p;
-  SK_TRY(lane_gate(h, ln, 1, st));
   { ProfScope ps(h, XT_PROF_STEM, st); SK_TRY(launch_stem(feats, sb, sf, stt, h->stem_w, h->stem_scale, h->stem_shift, X, dt, m.lens, B, T, st)); }
   SK_TRY(tap(h, "stem", X, act_bytes, st));
-  SK_TRY(lane_gate(h, ln, 2, st));
-  if (stop_here(2)) return SK_OK;
   int prev_li = 0;
   for (size_t bi = 0; bi < h->blocks.size(); ++bi) {
     Block& b = h->blocks[bi];
@@ -699,7 +676,6 @@ static int half_from_feats(xt_handle* h, Lane& ln, const float* feats, long sb, 
                "SE statistics workspace too small for %d x %d frames (xt_reserve)", B, T);
     }
     { ProfScope ps(h, b.c1.shape, st); SK_TRY(launch_conv(b.c1.shape, dt, a, st)); }
-    if (stop_launch((int)bi * 3 + 1)) return SK_OK;
     a.sc_wpack = nullptr;
     const void* shortcut = first ? SC : X;
     if (first && !fuse_sc && !inplace_sc) {  // 1x1 conv (stride s) + bn on the block input
@@ -715,7 +691,6 @@ static int half_from_feats(xt_handle* h, Lane& ln, const float* feats, long sb, 
       ProfScope ps(h, XT_PROF_SE_RES, st);
       SK_TRY(launch_se_pre(se, st));
     }
-    if (stop_launch((int)bi * 3 + 2)) return SK_OK;
     // conv2 + bn2, * gate, + shortcut, relu -> O2 (the block output)
     a.in = O1; a.wpack = b.c2.wpack; a.scale = b.c2.scale; a.shift = b.c2.shift; a.out = O2;
     a.se_part = nullptr; a.col_part = nullptr; a.edge = nullptr; a.gate = (const float*)ln.ws_gate.p; a.shortcut = shortcut;
@@ -725,12 +700,9 @@ static int half_from_feats(xt_handle* h, Lane& ln, const float* feats, long sb, 
       a.sc_wpack = b.sc_wfold; a.sc_scale = b.sc.scale; a.sc_shift = b.sc.shift;
     }
     { ProfScope ps(h, b.c2.shape, st); SK_TRY(launch_conv(b.c2.shape, dt, a, st)); }
-    if (stop_launch((int)bi * 3 + 3)) return SK_OK;
     std::swap(X, O2);
     const bool last_of_layer = (bi + 1 == h->blocks.size()) || (h->blocks[bi + 1].li != li);
     if (last_of_layer) {
-      SK_TRY(lane_gate(h, ln, 3 + li, st));
-      if (stop_here(3 + li)) return SK_OK;
       const std::string nm = "layer" + std::to_string(li + 1);
       SK_TRY(tap(h, nm.c_str(), X, (size_t)B * Hl[li] * wout * b.C * EB, st));
     }
@@ -762,8 +734,6 @@ static int half_from_feats(xt_handle* h, Lane& ln, const float* feats, long sb, 
   SK_TRY(launch_att_stats(X, xbf, (const float*)ln.ws_e.p, D, D, rs, (float*)ln.ws_pooled.p, B, st));
   }
   SK_TRY(tap(h, "pooled", ln.ws_pooled.p, (size_t)B * 2 * D * 4, st));
-  SK_TRY(lane_gate(h, ln, 7, st));
-  if (stop_here(7)) return SK_OK;
   GemmArgs e = gemm_args();  // lin_be + bn_be (xvector.py:578-581)
   e.A = ln.ws_pooled.p; e.lda = 2 * D; e.a_rows = B; e.W = h->emb_w; e.ldw = 2 * D; e.C = (float*)ln.ws_pre.p;
   e.ldc = h->cfg.emb_dim; e.M = B; e.N = h->cfg.emb_dim; e.K = 2 * D; e.scale = h->emb_scale; e.shift = h->emb_shift;
@@ -1083,10 +1053,6 @@ static int forward_wav(xt_handle* h, const void* d_wav, int pcm16, int64_t wav_l
   }
   SK_TRY(lane_frontend(h, l0, d_wav, pcm16, wav_ld, h_nsamples, B0, L, m0, st));
   SK_TRY(lane_trunk(h, l0, m0, d_emb, d_logits, st));
-  if (getenv("SIDEKIT_AMD_LANE_GATE")) {
-    if (!h->lane0_done) SK_HIP(hipEventCreateWithFlags(&h->lane0_done, hipEventDisableTiming));
-    SK_HIP(hipEventRecord(h->lane0_done, st));
-  }
   if (diag & 2) {
     SK_HIP(hipEventRecord(l1.fork, st));
     SK_HIP(hipStreamWaitEvent(s1, l1.fork, 0));
