@@ -314,47 +314,7 @@ void conv3x3_kernel(ConvArgs a) {
   if constexpr (RESIDENT) load_weights(0);
 
   const int tid0 = tid;
-  // PREFETCH (persistent shapes with the direct-store epilogue, every form but the in-place shortcut one): the epilogue does not
-  // touch the LDS image, so the NEXT tile's halo rows are requested as soon as this tile's k-loop has finished and land while the
-  // epilogue computes and stores -- DMA issue under HBM back-pressure and the epilogue were a tile's two longest phases and ran
-  // one after the other (3.7 k + 7.4 k of 15.9 k cycles per layer-1 tile).
-  constexpr bool PREFETCH = C::RESIDENT && C::DIRECT && C::SWZ && FORM != FORM_RESID_SC && !SC;
-  auto zero_positions = [&]() {  // the zero position after each row (and the one in front of the image): never touched by the DMA
-    for (int s = tid0; s < C::RIN * C::SPP; s += NTHREADS)
-      *reinterpret_cast<uint4*>(smem + C::IMG0 + (s / C::SPP) * C::RS + C::WIN * C::CB + (s % C::SPP) * 16) = make_uint4(0, 0, 0, 0);
-    if constexpr (C::LEAD) {
-      if (tid0 < C::SPP) *reinterpret_cast<uint4*>(smem + tid0 * 16) = make_uint4(0, 0, 0, 0);
-    }
-  };
-  auto stage_swz = [&](int work) {  // LDS-DMA of one work item's halo rows (swizzled image, one channel chunk)
-    int tid = tid0;
-    asm volatile("" : "+v"(tid));
-    const int lane = tid & 63;
-    const int b = work / tiles, tile = work % tiles;
-    const int hin_b = __builtin_amdgcn_readfirstlane(halve(a.lens.get(b), a.halvings_in));
-    const int hi0 = tile * C::TH * C::S - 1;
-    constexpr int NPIECE = C::RIN * C::PPR;
-    for (int it = (a.dbg & 4) ? NPIECE : wave; it < NPIECE; it += NWAVES) {
-      const int row = it / C::PPR, q = it % C::PPR;          // wave-uniform
-      const int hi = hi0 + row;
-      const bool rowok = hi >= 0 && hi < hin_b;
-      const unsigned char* rowbase = in + ((((size_t)b * a.Hin + hi) * C::WIN) * C::CIN) * C::EB;
-      const int slot = q * 64 + lane;
-      const unsigned char* src = reinterpret_cast<const unsigned char*>(a.zeros);
-      const int col = slot / C::SPP, cs = slot % C::SPP;
-      const int cc = cs ^ C::swz_key(row, col);
-      if (rowok) src = rowbase + col * (C::CIN * C::EB) + cc * 16;
-      if ((C::WIN * C::SPP) % 64 == 0 || slot < C::WIN * C::SPP)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(smem + C::IMG0 + row * C::RS + q * 1024), 16, 0, 0);
-    }
-  };
-  auto item_valid = [&](int work) {
-    const int b = work / tiles, tile = work % tiles;
-    const int hin_b = halve(a.lens.get(b), a.halvings_in);
-    return tile * C::TH < ((C::S == 2) ? ((hin_b + 1) >> 1) : hin_b);
-  };
-  auto do_item = [&](int work, bool first_item, int next_work) -> bool {  // returns whether the tile touched the LDS
+  auto do_item = [&](int work, bool first_item) -> bool {  // returns whether the tile touched the LDS
   // persistent form: hide the thread index from loop-invariant code motion -- hoisting every tile-independent DMA and
   // copy-out offset out of the tile loop costs ~40 registers (spills); recomputing them per tile is a few VALU ops
   int tid = tid0;
@@ -365,7 +325,7 @@ void conv3x3_kernel(ConvArgs a) {
   const int hin_b = __builtin_amdgcn_readfirstlane(halve(a.lens.get(b), a.halvings_in));  // wave-uniform: keep the row bounds in SGPRs
   const int hout_b = (C::S == 2) ? ((hin_b + 1) >> 1) : hin_b;
   if (ho0 >= hout_b) return false;  // nothing valid in this tile (its SE partial is never read)
-  if (!PREFETCH && !first_item) __syncthreads();  // the previous tile's copy-out has left the LDS
+  if (!first_item) __syncthreads();  // the previous tile's copy-out has left the LDS
   stamp(0);
   const int hi0 = ho0 * C::S - 1;
   f32x16 acc[C::MW][C::NW];
@@ -388,7 +348,7 @@ void conv3x3_kernel(ConvArgs a) {
     // every piece in flight at once).  A lane whose slot is a pad slot or a zero-padding position reads the zero page
     // (measured: masking those lanes off and zero-filling with ds_write instead is 20 % slower).
     constexpr int CPP = C::CB / 16, NPIECE = C::RIN * C::PPR;
-    if constexpr (C::SWZ && !PREFETCH) {
+    if constexpr (C::SWZ) {
       if (ch == 0) {  // the zero position after each row: never touched by the DMA, valid for every channel chunk
         for (int s = tid; s < C::RIN * C::SPP; s += NTHREADS)
           *reinterpret_cast<uint4*>(smem + C::IMG0 + (s / C::SPP) * C::RS + C::WIN * C::CB + (s % C::SPP) * 16) = make_uint4(0, 0, 0, 0);
@@ -397,7 +357,7 @@ void conv3x3_kernel(ConvArgs a) {
         }
       }
     }
-    for (int it = (PREFETCH || (a.dbg & 4)) ? NPIECE : wave; it < NPIECE; it += NWAVES) {   // PREFETCH: this tile's rows were requested during the previous tile
+    for (int it = (a.dbg & 4) ? NPIECE : wave; it < NPIECE; it += NWAVES) {
       const int row = it / C::PPR, q = it % C::PPR;          // wave-uniform
       const int hi = hi0 + row;
       const bool rowok = hi >= 0 && hi < hin_b;
@@ -549,10 +509,6 @@ void conv3x3_kernel(ConvArgs a) {
   //   residual   (conv2 of a block)            -> * gate[b][c] + shortcut -> ReLU -> store
   // The tile is transposed through the (now consumed) LDS halo buffer and leaves as whole 1-KiB, 16-B-per-lane NHWC
   // rows (direct 8-B stores ran at 2.9 TB/s); the shortcut rows are read the same way in the residual form.
-  if constexpr (PREFETCH) {
-    __syncthreads();                            // every wave has read its last fragment of this tile
-    if (next_work >= 0) stage_swz(next_work);
-  }
   constexpr int NC = C::WN * 32;                // channels of one out sub-tile
   constexpr int OPS = NC * C::EB + 16;          // out-tile position stride in LDS (padded against bank conflicts)
   static_assert(C::MT * OPS <= C::LDS, "out tile must fit the consumed input buffer");
@@ -945,28 +901,12 @@ void conv3x3_kernel(ConvArgs a) {
   stamp(6);
   return true;
   };
-  if constexpr (PREFETCH) {
-    auto next_valid = [&](int wi) {   // first valid item of this workgroup at or after wi, or -1
-      for (; wi < wcount; wi += wstride)
-        if (item_valid(wfirst + wi)) return wi;
-      return -1;
-    };
-    int wi = next_valid(bidx >> 3);
-    if (wi >= 0) {
-      zero_positions();
-      stage_swz(wfirst + wi);
-      while (wi >= 0) {
-        const int wn_ = next_valid(wi + wstride);
-        do_item(wfirst + wi, false, wn_ >= 0 ? wfirst + wn_ : -1);
-        wi = wn_;
-      }
-    }
-  } else if constexpr (RESIDENT) {
+  if constexpr (RESIDENT) {
     bool first_item = true;
     for (int wi = bidx >> 3; wi < wcount; wi += wstride)
-      if (do_item(wfirst + wi, first_item, -1)) first_item = false;
+      if (do_item(wfirst + wi, first_item)) first_item = false;
   } else {  // one work item per workgroup (no loop: its invariants would cost these kernels registers)
-    if ((bidx >> 3) < wcount) do_item(wfirst + (bidx >> 3), true, -1);
+    if ((bidx >> 3) < wcount) do_item(wfirst + (bidx >> 3), true);
   }
 }
 
