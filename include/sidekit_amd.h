@@ -97,9 +97,9 @@ int xt_features(xt_handle* h, const float* d_wav, int64_t wav_ld, const int32_t*
  * eval output is then the un-normalised linear6 output; the 'aam' branch always normalises (:903). */
 int xt_set_norm_embedding(xt_handle* h, int32_t on);
 
-/* Two-lane forward.  With lanes = 2 (the default; SIDEKIT_AMD_LANES=1 in the environment or xt_set_lanes(h, 1) turns it off) a
- * HalfResNet34 batch of >= 128 utterances is forwarded as two halves on two HIP streams (the caller's and one the handle owns):
- * one half's latency-bound kernels run under the other half's convolutions.  Results do not change (every kernel is batch-size
+/* Split forward.  With lanes = n (default 2, at most 4; SIDEKIT_AMD_LANES in the environment or xt_set_lanes) a HalfResNet34 batch
+ * of >= 128 utterances is forwarded as up to n parts of at least 64 utterances on n HIP streams (the caller's and n - 1 the handle
+ * owns): one part's latency-bound kernels run under another part's convolutions.  Results do not change (every kernel is batch-size
  * invariant).  lanes = 1 serialises the forward again, for profiles in which one kernel's duration has to mean something.
  * The reference has no counterpart: its forward is one
  * stream of cuDNN calls (sidekit/nnet/xvector.py:876-907). */

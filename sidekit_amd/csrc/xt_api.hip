@@ -83,7 +83,15 @@ struct Lane {
 
 static int lanes_from_env() {
   const char* e = getenv("SIDEKIT_AMD_LANES");
-  return (e && atoi(e) == 1) ? 1 : 2;
+  const int n = e ? atoi(e) : 2;
+  return n < 1 ? 1 : (n > 4 ? 4 : n);
+}
+
+// parts a batch of B utterances is forwarded in: at most `lanes`, each of at least LANE_MIN utterances
+static int lane_parts(int lanes, int B, int lane_min) {
+  int n = B / lane_min;
+  n = n < 1 ? 1 : n;
+  return n < lanes ? n : lanes;
 }
 
 }  // namespace sk
@@ -124,14 +132,15 @@ struct xt_handle {
   struct TdnnLayer { float *w, *bias, *scale, *shift; int cin, cout, k, dil; };
   std::vector<TdnnLayer> tdnn;
 
-  // workspace: two lanes.  Lane 0 runs on the caller's stream and is sized for the whole batch; lane 1 (own stream, sized for half a
-  // batch) exists only while the two-lane forward is on: a batch of >= LANE_MIN utterances is then forwarded as two halves on two HIP
-  // streams, so that one half's latency-bound kernels (SE gates, pooling, front-end: 0.8 ms of a 6.5-ms step) run under the other
-  // half's convolutions.  Utterances are independent and every kernel is batch-size invariant, so the x-vectors are the same bits.
+  // workspace: lanes.  Lane 0 runs on the caller's stream and is sized for the whole batch; lanes 1 .. n-1 (own streams, sized for a
+  // part of a batch) exist only while the split forward is on: a batch of >= 2 LANE_MIN utterances is then forwarded as n parts on n
+  // HIP streams, so that one part's latency-bound kernels (SE gates, pooling, front-end: 0.8 ms of a 6.5-ms step) run under another
+  // part's convolutions.  Utterances are independent and every kernel is batch-size invariant, so the x-vectors are the same bits.
   std::vector<std::pair<int, int64_t>> reserved;   // (batch, samples) shapes xt_reserve has sized the workspace for: a batch runs when one of them covers it in BOTH dimensions
-  Lane lane[2];
-  int lanes = lanes_from_env();                    // 1: serial (profiling: per-kernel durations mean something), 2: two-lane forward
-  static constexpr int LANE_MIN = 128;
+  static constexpr int MAX_LANES = 4;
+  Lane lane[MAX_LANES];
+  int lanes = lanes_from_env();                    // 1: serial (profiling: per-kernel durations mean something), 2 (default) .. 4: that many parts of a batch side by side
+  static constexpr int LANE_MIN = 64;              // utterances per lane below which a batch is not split further
   bool norm_embedding = true;
   // per-kernel-class HIP-event profile (xt_set_profile)
   uint32_t profile = 0;   // bit (slot + 1) per bracketed slot; 1 = all
@@ -966,23 +975,27 @@ static int reserve_lane(xt_handle* h, Lane& ln, int32_t max_batch, int64_t max_s
   return SK_OK;
 }
 
-// the second lane takes the smaller half of a split batch
-static int reserve_second_lane(xt_handle* h, int32_t max_batch, int64_t max_samples) {
-  if (h->lanes < 2 || max_batch < xt_handle::LANE_MIN || h->cfg.arch != XT_ARCH_HALFRESNET34) return SK_OK;
-  Lane& l1 = h->lane[1];
-  if (!l1.stream) {
-    SK_HIP(hipStreamCreateWithFlags(&l1.stream, hipStreamNonBlocking));
-    SK_HIP(hipEventCreateWithFlags(&l1.fork, hipEventDisableTiming));
-    SK_HIP(hipEventCreateWithFlags(&l1.join, hipEventDisableTiming));
+// lanes 1 .. n-1 take the later parts of a split batch (part k of n: rows [k B / n, (k + 1) B / n))
+static int reserve_side_lanes(xt_handle* h, int32_t max_batch, int64_t max_samples) {
+  if (h->cfg.arch != XT_ARCH_HALFRESNET34) return SK_OK;
+  const int n = lane_parts(h->lanes, max_batch, xt_handle::LANE_MIN);
+  for (int k = 1; k < n; ++k) {
+    Lane& lk = h->lane[k];
+    if (!lk.stream) {
+      SK_HIP(hipStreamCreateWithFlags(&lk.stream, hipStreamNonBlocking));
+      SK_HIP(hipEventCreateWithFlags(&lk.fork, hipEventDisableTiming));
+      SK_HIP(hipEventCreateWithFlags(&lk.join, hipEventDisableTiming));
+    }
+    SK_TRY(reserve_lane(h, lk, (max_batch + n - 1) / n, max_samples));
   }
-  return reserve_lane(h, l1, max_batch / 2, max_samples);
+  return SK_OK;
 }
 
 int xt_reserve(xt_handle* h, int32_t max_batch, int64_t max_samples) {
   SK_CHECK(h && max_batch > 0 && max_samples > 0, SK_EARG, "xt_reserve: bad arguments");
   SK_HIP(hipSetDevice(h->device));
   SK_TRY(reserve_lane(h, h->lane[0], max_batch, max_samples));
-  SK_TRY(reserve_second_lane(h, max_batch, max_samples));
+  SK_TRY(reserve_side_lanes(h, max_batch, max_samples));
   bool covered = false;
   for (auto& r : h->reserved) covered = covered || (r.first >= max_batch && r.second >= max_samples);
   if (!covered) h->reserved.push_back({max_batch, max_samples});
@@ -1024,43 +1037,35 @@ static int forward_wav(xt_handle* h, const void* d_wav, int pcm16, int64_t wav_l
   SK_CHECK(d_wav && d_emb && wav_ld >= L, SK_EARG, "xt_forward: bad buffers");
   hipStream_t st = (hipStream_t)stream;
   Lane& l0 = h->lane[0];
-  Lane& l1 = h->lane[1];
-  const bool split = h->lanes > 1 && !h->debug && B >= xt_handle::LANE_MIN && l1.stream && h->cfg.arch == XT_ARCH_HALFRESNET34;
+  int n = (h->debug || h->cfg.arch != XT_ARCH_HALFRESNET34) ? 1 : lane_parts(h->lanes, B, xt_handle::LANE_MIN);
+  while (n > 1 && !h->lane[n - 1].stream) --n;          // lanes that xt_reserve has not created yet (handle switched after its last reserve)
   BatchMeta m0;
-  if (!split) {
+  if (n == 1) {
     SK_TRY(lane_frontend(h, l0, d_wav, pcm16, wav_ld, h_nsamples, B, L, m0, st));
     return lane_trunk(h, l0, m0, d_emb, d_logits, st);
   }
-  // Two lanes: rows [0, B0) on the caller's stream, rows [B0, B) on the handle's second stream; the second lane starts behind
-  // everything queued on the caller's stream so far (its input may still be in flight) and the caller's stream continues only
-  // once both halves are done.  Round 3 found the first version of this giving a few wrong spectrum bins per batch in the
-  // second lane: the STFT kernel's SLP-formed packed-f32 instructions (v_pk_add_f32 / v_pk_mul_f32 with op_sel / neg modifiers)
+  // n lanes: part k = rows [k B / n, (k + 1) B / n); part 0 on the caller's stream, the others on streams the handle owns.  A side
+  // lane starts behind everything queued on the caller's stream so far (its input may still be in flight) and the caller's stream
+  // continues only once every part is done.  Round 3 found the first version of this giving a few wrong spectrum bins per batch in
+  // the second lane: the STFT kernel's SLP-formed packed-f32 instructions (v_pk_add_f32 / v_pk_mul_f32 with op_sel / neg modifiers)
   // misbehave on MI355X beside another stream's dense bf16 MFMAs.  The library is built without them now (csrc/Makefile); the
-  // evidence is under profiles/r03_two_lane_frontend_hazard.txt and tests/test_gpu_fullsize.py repeats the two-lane forward
-  // against the serial one.  SIDEKIT_AMD_LANE_FRONTENDS_FIRST=1 runs both front-ends on the caller's stream ahead of the fork.
-  const int B0 = B - B / 2, B1 = B / 2;
+  // evidence is under profiles/r03_two_lane_frontend_hazard.txt and tests/test_gpu_fullsize.py repeats the split forward against
+  // the serial one.
   const size_t eb = pcm16 ? 2 : 4;
-  BatchMeta m1;
-  static const int diag = getenv("SIDEKIT_AMD_LANE_DIAG") ? atoi(getenv("SIDEKIT_AMD_LANE_DIAG")) : 0;   // diagnostics: 1 = second lane on the caller's stream, 2 = second lane starts after the first has finished
-  static const bool fe_first = getenv("SIDEKIT_AMD_LANE_FRONTENDS_FIRST") != nullptr;
-  hipStream_t s1 = (diag & 1) ? st : l1.stream;
-  const void* wav1 = (const unsigned char*)d_wav + (size_t)B0 * wav_ld * eb;
-  const int32_t* ns1 = h_nsamples ? h_nsamples + B0 : nullptr;
-  if (fe_first) SK_TRY(lane_frontend(h, l1, wav1, pcm16, wav_ld, ns1, B1, L, m1, st));
-  if (!(diag & 2)) {
-    SK_HIP(hipEventRecord(l1.fork, st));
-    SK_HIP(hipStreamWaitEvent(s1, l1.fork, 0));
+  for (int k = 1; k < n; ++k) {
+    SK_HIP(hipEventRecord(h->lane[k].fork, st));
+    SK_HIP(hipStreamWaitEvent(h->lane[k].stream, h->lane[k].fork, 0));
   }
-  SK_TRY(lane_frontend(h, l0, d_wav, pcm16, wav_ld, h_nsamples, B0, L, m0, st));
-  SK_TRY(lane_trunk(h, l0, m0, d_emb, d_logits, st));
-  if (diag & 2) {
-    SK_HIP(hipEventRecord(l1.fork, st));
-    SK_HIP(hipStreamWaitEvent(s1, l1.fork, 0));
+  for (int k = 0; k < n; ++k) {
+    Lane& lk = h->lane[k];
+    const int r0 = (int)((long)k * B / n), r1 = (int)((long)(k + 1) * B / n);
+    hipStream_t sk_ = k ? lk.stream : st;
+    BatchMeta mk;
+    SK_TRY(lane_frontend(h, lk, (const unsigned char*)d_wav + (size_t)r0 * wav_ld * eb, pcm16, wav_ld, h_nsamples ? h_nsamples + r0 : nullptr, r1 - r0, L, mk, sk_));
+    SK_TRY(lane_trunk(h, lk, mk, d_emb + (size_t)r0 * h->cfg.emb_dim, d_logits ? d_logits + (size_t)r0 * h->cfg.n_spk : nullptr, sk_));
+    if (k) SK_HIP(hipEventRecord(lk.join, lk.stream));
   }
-  if (!fe_first) SK_TRY(lane_frontend(h, l1, wav1, pcm16, wav_ld, ns1, B1, L, m1, s1));
-  SK_TRY(lane_trunk(h, l1, m1, d_emb + (size_t)B0 * h->cfg.emb_dim, d_logits ? d_logits + (size_t)B0 * h->cfg.n_spk : nullptr, s1));
-  SK_HIP(hipEventRecord(l1.join, s1));
-  SK_HIP(hipStreamWaitEvent(st, l1.join, 0));
+  for (int k = 1; k < n; ++k) SK_HIP(hipStreamWaitEvent(st, h->lane[k].join, 0));
   return SK_OK;
 }
 
@@ -1117,11 +1122,11 @@ int xt_set_norm_embedding(xt_handle* h, int32_t on) {
 }
 
 int xt_set_lanes(xt_handle* h, int32_t lanes) {
-  SK_CHECK(h && (lanes == 1 || lanes == 2), SK_EARG, "xt_set_lanes: 1 (serial) or 2");
+  SK_CHECK(h && lanes >= 1 && lanes <= xt_handle::MAX_LANES, SK_EARG, "xt_set_lanes: 1 (serial) .. %d", xt_handle::MAX_LANES);
   h->lanes = lanes;
   if (lanes > 1) {   // size the second lane for every shape reserved while the handle was serial
     SK_HIP(hipSetDevice(h->device));
-    for (auto& r : h->reserved) SK_TRY(reserve_second_lane(h, r.first, r.second));
+    for (auto& r : h->reserved) SK_TRY(reserve_side_lanes(h, r.first, r.second));
   }
   return SK_OK;
 }

@@ -56,6 +56,8 @@ def test_two_lane_forward_is_bit_identical_to_the_serial_one(model, dtype):
             model.set_lanes(2)
             assert model.get_lanes() == 2
             two = [model(wav, is_eval=True, lengths=lens) for _ in range(8 if dtype == "bf16" else 3)]   # steady state: both lanes reuse their workspaces
+            model.set_lanes(4)                                              # four parts of >= 64 utterances where the batch allows
+            two += [model(wav, is_eval=True, lengths=lens) for _ in range(4 if dtype == "bf16" else 2)]
             model.set_lanes(1)
             lg1, e1 = model(wav, is_eval=True, lengths=lens)
             torch.cuda.synchronize()

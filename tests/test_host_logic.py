@@ -192,3 +192,20 @@ def test_histogram_eer_is_the_rocch_eer_of_the_binned_scores():
     assert eer_from_histograms(a, b) == 0
     a[:], b[:] = 1, 1
     assert abs(eer_from_histograms(a, b) - 0.5) < 1e-12
+
+
+def test_shard_extract_score_load_plda(tmp_path, golden_dir):
+    """`bin/shard_extract_score.load_plda`: (mu, F, Sigma) from the config-5 fixture (.npz, the reference's FactorAnalyser.plda output) and
+    from a SIDEKIT PLDA HDF5 file written by `sidekit_io.write_plda_hdf5` -- the same arrays either way."""
+    import os
+    from sidekit_amd import sidekit_io
+    from sidekit_amd.bin.shard_extract_score import load_plda
+    fx = numpy.load(os.path.join(golden_dir, "config5.npz"))
+    mu, F, Sigma = load_plda(os.path.join(golden_dir, "config5.npz"))
+    assert mu.shape == (256,) and F.shape == (256, 128) and Sigma.shape == (256, 256) and mu.dtype == numpy.float64
+    numpy.testing.assert_array_equal(F, fx["F"])
+    sidekit_io.write_plda_hdf5((mu, F, numpy.zeros((256, 0)), Sigma), str(tmp_path / "plda.h5"))
+    mu2, F2, Sigma2 = load_plda(str(tmp_path / "plda.h5"))
+    numpy.testing.assert_array_equal(mu2, mu)
+    numpy.testing.assert_array_equal(F2, F)
+    numpy.testing.assert_array_equal(Sigma2, Sigma)
