@@ -289,7 +289,11 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs g) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int wm = wave >> 1, wn = wave & 1;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  // 1-D grid: the NT column tiles of one row tile sit 8 block ids apart -- the same XCD under round-robin dispatch, started together --
+  // so the second read of the A rows (67 MB for attention.0 at B = 256) is an L2 hit instead of a second trip to HBM
+  const int nt_ = (g.N + BN - 1) / BN;
+  const int n0 = (int)((blockIdx.x >> 3) % nt_) * BN, m0 = (int)(((blockIdx.x >> 3) / nt_) * 8 + (blockIdx.x & 7)) * BM;
+  if (m0 >= g.M) return;
   // staging: 64 rows x 8 chunks of 8 bf16 -> 512 chunks per operand, 2 per thread
   const int srow = tid >> 3, sk8 = (tid & 7) * 8;
   uint4 ra[2], rw[2];
@@ -363,7 +367,7 @@ int launch_gemm(const GemmArgs& g_in, hipStream_t s) {
   SK_CHECK(g.K % 4 == 0 && g.ldw % 4 == 0, SK_EARG, "gemm: K=%d / ldw=%ld must be multiples of 4", g.K, g.ldw);
   SK_CHECK(g.a_mode != A_PLAIN || (g.lda % 4 == 0 && g.kc % 4 == 0), SK_EARG, "gemm: lda/kc alignment");
   if (g.W_bf16 && g.a_mode == A_PLAIN && g.kc == 0 && g.K % 8 == 0 && g.lda % 8 == 0 && g.ldw % 8 == 0 && g.ksplit == 1) {
-    hipLaunchKernelGGL(gemm_bf16_kernel, dim3(cdiv(g.M, BM), cdiv(g.N, BN)), dim3(256), 0, s, g);
+    hipLaunchKernelGGL(gemm_bf16_kernel, dim3((unsigned)(cdiv(cdiv(g.M, BM), 8) * 8 * cdiv(g.N, BN))), dim3(256), 0, s, g);
     SK_HIP(hipGetLastError());
     return SK_OK;
   }
