@@ -98,6 +98,29 @@ def full_plda_scores(enroll, test, mu, F, G, Sigma, p_known=0.0, scaling_factor=
     return _open_set(s, p_known) if p_known != 0 else s
 
 
+def mahalanobis_scores(enroll, test, m):
+    """iv_scoring.py:145-149, the reference's own loop: per model, ``-0.5 * sum((t - e) M * (t - e))`` over the test rows."""
+    s = numpy.zeros((enroll.shape[0], test.shape[0]))
+    for i in range(enroll.shape[0]):
+        d = test - enroll[i]
+        s[i] = -0.5 * numpy.sum(d.dot(m) * d, axis=1)
+    return s
+
+
+def two_covariance_scores(enroll, test, W, B):
+    """iv_scoring.py:194-205 (column vectors there, rows here): ``(e + t)' G (e + t) - t' H t - e' H e``."""
+    iW, iB = scipy.linalg.inv(W), scipy.linalg.inv(B)
+    G = iW.dot(scipy.linalg.inv(iB + 2 * iW)).dot(iW)
+    H = iW.dot(scipy.linalg.inv(iB + iW)).dot(iW)
+    s2 = numpy.sum(test.dot(H) * test, axis=1)
+    s3 = numpy.sum(enroll.dot(H) * enroll, axis=1)
+    s = numpy.zeros((enroll.shape[0], test.shape[0]))
+    for i in range(enroll.shape[0]):
+        a = test + enroll[i]
+        s[i] = numpy.sum(a.dot(G) * a, axis=1) - s2 - s3[i]
+    return s
+
+
 def asnorm(enrol_xv, cohort_xv, topk=200):
     """score_normalization.py:120-140 (torch, float32)."""
     import torch

@@ -24,6 +24,7 @@ _LAZY = {
     "logit_effective_prior": "bosaris", "fast_minDCF": "bosaris",
     "StatServer": "statserver",
     "cosine_scoring": "iv_scoring", "PLDA_scoring": "iv_scoring", "fast_PLDA_scoring": "iv_scoring", "full_PLDA_scoring": "iv_scoring",
+    "mahalanobis_scoring": "iv_scoring", "two_covariance_scoring": "iv_scoring",
     "asnorm": "score_normalization",
     "write_matrix_hdf5": "sidekit_io", "read_plda_hdf5": "sidekit_io", "write_plda_hdf5": "sidekit_io",
 }

@@ -131,9 +131,11 @@ struct FftArgs {
   int M, t_max, hop;
   const int* row_b; const int* row_t;          // optional ragged row map
   float preemph;
-  // fused mel projection (mel_w != nullptr): instead of P the kernel writes logmel[m][j] = log(sum_k fb[k][j] P[k] + 1e-6);
-  // every filter is a short run of bins (triangles: <= 31 of 513), stored compacted as mel_w[i][j] = fb[mel_start[j] + i][j]
-  const float* mel_w; const int* mel_start; const int* mel_len; int n_mels;
+  // fused mel projection (mel_cw != nullptr): instead of P the kernel writes logmel[m][j] = log(sum_k fb[k][j] P[k] + 1e-6).
+  // Every filter is a short run of bins (triangles: <= 31 of 513) cut into chunks of 8 taps: chunk c = bins [mel_ck0[c], + 8) with
+  // weights mel_cw[c][0..8) (zero beyond the filter's run); filter j owns the consecutive chunks [cb, cb + nc), mel_fmeta[j] = cb | nc << 16;
+  // mel_chunks is padded to a multiple of 64 with all-zero chunks
+  const float* mel_cw; const int* mel_ck0; const int* mel_fmeta; int mel_chunks; int n_mels;
   float* logmel; long ldl;
 };
 int launch_stft_power_fft(const FftArgs& a, hipStream_t s);

@@ -114,7 +114,7 @@ struct xt_handle {
   float* d_window = nullptr;
   float* d_basis = nullptr;  // [2*nbp][win]
   float* d_fbT = nullptr;    // [n_mels][nbp]
-  float* d_mel_w = nullptr; int* d_mel_start = nullptr; int* d_mel_len = nullptr; bool mel_fused = false;   // compacted bank (frontend_fft.hip)
+  float* d_mel_cw = nullptr; int* d_mel_ck0 = nullptr; int* d_mel_fmeta = nullptr; int mel_chunks = 0; bool mel_fused = false;   // bank as 8-tap chunks (frontend_fft.hip)
   float* d_dctT = nullptr;   // [n_out][n_mels] (MFCC)
   float* d_tw512 = nullptr;  // FFT twiddles: the n_fft/2-point complex transform's ...
   float* d_tw1024 = nullptr; // ... and the real-FFT split's
@@ -299,7 +299,7 @@ static int build_frontend(xt_handle* h) {
   for (int j = 0; j < nb; ++j)
     for (int m = 0; m < f.n_mels; ++m) fbT[(size_t)m * h->nbp + j] = fb[(size_t)j * f.n_mels + m];
   SK_TRY(upload_f(h, fbT, &h->d_fbT));
-  {  // compacted filters for the projection fused into the FFT kernel: filter j = bins [start, start + len)
+  {  // the bank for the projection fused into the FFT kernel: filter m = bins [st, st + ln) cut into 8-tap chunks (kernels.h, FftArgs)
     std::vector<int> st(f.n_mels, 0), ln(f.n_mels, 0);
     int maxlen = 0;
     for (int m = 0; m < f.n_mels; ++m) {
@@ -309,14 +309,25 @@ static int build_frontend(xt_handle* h) {
       if (hi >= lo) { st[m] = lo; ln[m] = hi - lo + 1; }
       maxlen = ln[m] > maxlen ? ln[m] : maxlen;
     }
-    h->mel_fused = maxlen > 0 && maxlen <= 64;   // a dense or very wide bank stays on the GEMM path
-    if (h->mel_fused) {
-      std::vector<float> wc((size_t)((maxlen + 7) / 8 * 8) * f.n_mels, 0.f);   // zero rows up to a multiple of 8 taps
-      for (int m = 0; m < f.n_mels; ++m)
-        for (int i = 0; i < ln[m]; ++i) wc[(size_t)i * f.n_mels + m] = fb[(size_t)(st[m] + i) * f.n_mels + m];
-      SK_TRY(upload_f(h, wc, &h->d_mel_w));
-      SK_TRY(upload(h, st.data(), st.size() * sizeof(int), (void**)&h->d_mel_start));
-      SK_TRY(upload(h, ln.data(), ln.size() * sizeof(int), (void**)&h->d_mel_len));
+    if (maxlen > 0 && maxlen <= 64) {   // a dense or very wide bank stays on the GEMM path
+      std::vector<float> cw; std::vector<int> ck0, fmeta(f.n_mels, 0);
+      for (int m = 0; m < f.n_mels; ++m) {
+        const int nc = ln[m] > 0 ? (ln[m] + 7) / 8 : 1, cb = (int)ck0.size();
+        fmeta[m] = cb | (nc << 16);
+        for (int q = 0; q < nc; ++q) {
+          ck0.push_back(ln[m] > 0 ? st[m] + 8 * q : 0);
+          for (int i = 8 * q; i < 8 * q + 8; ++i) cw.push_back(i < ln[m] ? fb[(size_t)(st[m] + i) * f.n_mels + m] : 0.f);
+        }
+      }
+      while (ck0.size() % 64) { ck0.push_back(0); cw.insert(cw.end(), 8, 0.f); }
+      h->mel_chunks = (int)ck0.size();
+      // the power row (n_fft / 2 + 8 floats, rounded up) and the chunk sums live in the transform's LDS buffer (2 * (n_fft / 2 + n_fft / 16) floats)
+      h->mel_fused = h->mel_chunks + 8 <= 2 * (f.n_fft / 2 + f.n_fft / 16) - (f.n_fft / 2 + 16) && h->mel_chunks < 65536;
+      if (h->mel_fused) {
+        SK_TRY(upload_f(h, cw, &h->d_mel_cw));
+        SK_TRY(upload(h, ck0.data(), ck0.size() * sizeof(int), (void**)&h->d_mel_ck0));
+        SK_TRY(upload(h, fmeta.data(), fmeta.size() * sizeof(int), (void**)&h->d_mel_fmeta));
+      }
     }
   }
   {  // twiddles of the n_fft-point real FFT (frontend_fft.hip), rounded once from double: the n_fft/2-point complex transform's
@@ -587,9 +598,9 @@ static int frontend_rows(xt_handle* h, Lane& ln, const void* d_wav, int pcm16, i
     fa.tw512 = h->d_tw512; fa.tw1024 = h->d_tw1024; fa.P = (float*)ln.ws_S.p; fa.ldp = h->nbp; fa.M = M; fa.t_max = m.T; fa.hop = f.hop;
     fa.row_b = m.d_row_b; fa.row_t = m.d_row_t; fa.preemph = 0.97f;
     SK_CHECK((size_t)M * h->nbp * 4 <= ln.ws_S.bytes, SK_EWORKSPACE, "spectrum workspace too small (xt_reserve)");
-    fa.mel_w = nullptr; fa.mel_start = nullptr; fa.mel_len = nullptr; fa.n_mels = 0; fa.logmel = nullptr; fa.ldl = 0;
+    fa.mel_cw = nullptr; fa.mel_ck0 = nullptr; fa.mel_fmeta = nullptr; fa.mel_chunks = 0; fa.n_mels = 0; fa.logmel = nullptr; fa.ldl = 0;
     if (h->mel_fused && !h->mel_gemm) {  // power spectrum stays in LDS, the kernel writes log-mel rows
-      fa.mel_w = h->d_mel_w; fa.mel_start = h->d_mel_start; fa.mel_len = h->d_mel_len; fa.n_mels = f.n_mels;
+      fa.mel_cw = h->d_mel_cw; fa.mel_ck0 = h->d_mel_ck0; fa.mel_fmeta = h->d_mel_fmeta; fa.mel_chunks = h->mel_chunks; fa.n_mels = f.n_mels;
       fa.logmel = logmel; fa.ldl = f.n_mels;
       have_logmel = true;
     }

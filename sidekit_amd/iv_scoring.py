@@ -1,5 +1,6 @@
 """Trial scoring -- mirror of ``sidekit/iv_scoring.py``: ``cosine_scoring`` (:63-113), ``PLDA_scoring``
-(:215-269), ``full_PLDA_scoring`` (:272-368), ``fast_PLDA_scoring`` (:370-477).
+(:215-269), ``full_PLDA_scoring`` (:272-368), ``fast_PLDA_scoring`` (:370-477), and -- beyond SURVEY 8's rows, because they are
+the same device entry point with other matrices -- ``mahalanobis_scoring`` (:116-156) and ``two_covariance_scoring`` (:159-213).
 
 The trial matrix is computed on the GPU through the C ABI (``sc_cosine``: f32 MFMA GEMM;
 ``sc_plda_fast``: float64 tiled GEMM with the quadratic terms and the constant fused in the
@@ -228,3 +229,53 @@ def fast_PLDA_scoring(enroll, test, ndx, mu, F, Sigma, test_uncertainty=None, Vt
     if p_known != 0:
         score.scoremat = _open_set(score.scoremat, p_known)
     return score
+
+
+def _prepared(enroll, test, ndx, check_missing):
+    """Shared head of the two functions below (iv_scoring.py:134-143,183-192): duplicate models averaged with a warning, missing
+    models / segments dropped.  The reference works on the caller's objects (its alignment reorders them in place); here copies."""
+    enroll, test = copy.deepcopy(enroll), copy.deepcopy(test)
+    if not numpy.unique(enroll.modelset).shape == enroll.modelset.shape:
+        logging.warning("Enrollment models are not unique, average i-vectors")
+        enroll = enroll.mean_stat_per_model()
+    clean_ndx = _check_missing_model(enroll, test, ndx) if check_missing else ndx
+    return enroll, test, clean_ndx
+
+
+def _scores(scoremat, clean_ndx):
+    score = Scores()
+    score.scoremat = scoremat
+    score.modelset = clean_ndx.modelset
+    score.segset = clean_ndx.segset
+    score.scoremask = clean_ndx.trialmask
+    return score
+
+
+def mahalanobis_scoring(enroll, test, ndx, m, check_missing=True, device=None):
+    """``-0.5 (e - t)' M (e - t)`` for every trial (iv_scoring.py:116-156; the reference loops over models on the host).  Expanded it is
+    the PLDA kernel's form with ``Phi = -sym(M)``, ``Psi = sym(M)``, no constant: one ``sc_plda_fast`` call, float64."""
+    assert isinstance(enroll, StatServer), 'First parameter should be a StatServer'
+    assert isinstance(test, StatServer), 'Second parameter should be a StatServer'
+    assert isinstance(ndx, Ndx), 'Third parameter should be an Ndx'
+    assert enroll.stat1.shape[1] == test.stat1.shape[1], 'I-vectors dimension mismatch'
+    assert enroll.stat1.shape[1] == m.shape[0], 'I-vectors and Mahalanobis matrix dimension mismatch'
+    enroll, test, clean_ndx = _prepared(enroll, test, ndx, check_missing)
+    ms = 0.5 * (numpy.asarray(m, dtype=numpy.float64) + numpy.asarray(m, dtype=numpy.float64).T)
+    return _scores(plda_matrix(enroll.stat1, test.stat1, -ms, ms, 0.0, 1.0, device), clean_ndx)
+
+
+def two_covariance_scoring(enroll, test, ndx, W, B, check_missing=True, device=None):
+    """Two-covariance scores (iv_scoring.py:159-213): ``(e + t)' G (e + t) - t' H t - e' H e`` with ``G = iW (iB + 2 iW)^-1 iW``,
+    ``H = iW (iB + iW)^-1 iW`` from the host's float64 algebra, i.e. ``Phi = 2 sym(G - H)``, ``Psi = G + G'`` in the PLDA kernel's form."""
+    assert isinstance(enroll, StatServer), 'First parameter should be a directory'
+    assert isinstance(test, StatServer), 'Second parameter should be a StatServer'
+    assert isinstance(ndx, Ndx), 'Third parameter should be an Ndx'
+    assert enroll.stat1.shape[1] == test.stat1.shape[1], 'I-vectors dimension mismatch'
+    assert enroll.stat1.shape[1] == W.shape[0], 'I-vectors and co-variance matrix dimension mismatch'
+    assert enroll.stat1.shape[1] == B.shape[0], 'I-vectors and co-variance matrix dimension mismatch'
+    enroll, test, clean_ndx = _prepared(enroll, test, ndx, check_missing)
+    iW, iB = scipy.linalg.inv(W), scipy.linalg.inv(B)
+    G = iW.dot(scipy.linalg.inv(iB + 2 * iW)).dot(iW)
+    H = iW.dot(scipy.linalg.inv(iB + iW)).dot(iW)
+    GH = G - H
+    return _scores(plda_matrix(enroll.stat1, test.stat1, GH + GH.T, G + G.T, 0.0, 1.0, device), clean_ndx)

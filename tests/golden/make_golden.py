@@ -323,6 +323,18 @@ def scoring_fixtures(mods, out):
     assert numpy.array_equal(og, gh) and numpy.array_equal(ow, wd) and numpy.array_equal(oh, hg)
     pm2, pf2_ = det.rocch(tar, non)
     fx["cos_eer"] = det.rocch2eer(pm2, pf2_)
+    # beyond SURVEY 8's rows: Mahalanobis and two-covariance scoring (iv_scoring.py:116-213), same trial list (these two reorder
+    # the caller's StatServers in place, hence the fresh copies); new random draws come last so the older keys regenerate unchanged
+    Mm = rs.randn(D, D) / numpy.sqrt(D)
+    Mm = Mm.dot(Mm.T) + 0.3 * numpy.eye(D)
+    Ww = rs.randn(D, D) / numpy.sqrt(D)
+    Ww = Ww.dot(Ww.T) + 0.5 * numpy.eye(D)
+    Bb = rs.randn(D, D) / numpy.sqrt(D)
+    Bb = Bb.dot(Bb.T) + 0.2 * numpy.eye(D)
+    mh = ivs.mahalanobis_scoring(make_sts(enr_ids, enr_ids, E), make_sts(tst_ids, tst_ids, T), ndx, Mm)
+    tc = ivs.two_covariance_scoring(make_sts(enr_ids, enr_ids, E), make_sts(tst_ids, tst_ids, T), ndx, Ww, Bb)
+    assert list(mh.modelset) == list(sc.modelset) and list(tc.segset) == list(sc.segset)
+    fx.update(maha_M=Mm, maha_scoremat=mh.scoremat, twocov_W=Ww, twocov_B=Bb, twocov_scoremat=tc.scoremat)
     numpy.savez_compressed(os.path.join(out, "scoring.npz"), **fx)
     print("scoring.npz", sorted(fx))
 

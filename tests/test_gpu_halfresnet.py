@@ -62,6 +62,38 @@ def test_golden_features_to_embedding(model, fx, tag):
     assert torch.allclose(emb.norm(dim=1), torch.ones(B, device=emb.device), atol=1e-5)
 
 
+def _coloured(seed, n_utt, n):
+    """Speech-like dynamic range: white noise through a one-pole low-pass (high bands ~40 dB under the low ones) plus two tones."""
+    g = torch.Generator().manual_seed(seed)
+    w = torch.randn(n_utt, n, generator=g, dtype=torch.float64)
+    x = torch.zeros_like(w)
+    acc = torch.zeros(n_utt, dtype=torch.float64)
+    for i in range(n):                                               # y[i] = 0.95 y[i-1] + w[i]
+        acc = 0.95 * acc + w[:, i]
+        x[:, i] = acc
+    t = torch.arange(n, dtype=torch.float64) / 16000.0
+    x = 0.02 * x + 0.3 * torch.sin(2 * numpy.pi * 440.0 * t) + 0.05 * torch.sin(2 * numpy.pi * 3000.0 * t)
+    return x
+
+
+def test_front_end_accuracy_against_the_float64_oracle(model, capsys):
+    """The f32 front-end kernel (real FFT, fused mel projection, log, CMVN) against the oracle evaluated in float64 on signals with a
+    large dynamic range, ragged lengths included (reflect-padded first / last frames, frames beyond the end): the error budget of
+    the f32 arithmetic itself, independent of the oracle's own f32 rounding."""
+    lens = [16000, 15999, 8000 + 77, 600]
+    x64 = _coloured(3, len(lens), max(lens))
+    got = model.features(x64.float().cuda(), lengths=lens).double().cpu()
+    worst = 0.0
+    for i, n in enumerate(lens):
+        ref = ofe.melspec_frontend(x64[i, :n].float().double())[0]      # the same f32 samples, float64 arithmetic from there on
+        t = 1 + n // 160
+        err = (got[i, :, :t] - ref).abs().max().item()
+        worst = max(worst, err)
+        assert err < 1e-4, (i, n, err)                                  # CMVN'ed log-mel values are O(1)
+    with capsys.disabled():
+        print(f"  [front-end vs float64 oracle: max abs error {worst:.2e}]", end="")
+
+
 def test_golden_wav_to_embedding(model, fx):
     x = torch.from_numpy(fx["wav_pcm16"].astype(numpy.float32) / 32768.0)
     feats = model.preprocessor(x.cuda(), is_eval=True)                # MelSpecFrontEnd.forward

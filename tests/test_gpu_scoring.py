@@ -76,6 +76,28 @@ def test_plda_scoring_golden(gpu, fx, caplog):
         iv_scoring.PLDA_scoring(enroll, test, ndx, mu, F[:-1], G, Sigma)
 
 
+def test_mahalanobis_and_two_covariance_golden(gpu, fx):
+    """iv_scoring.py:116-213 through the same ``sc_plda_fast`` launch pair; scores of magnitude ~600, expanded quadratic form, so the
+    tolerance is relative to that scale (float64 cancellation, not a precision choice)."""
+    enroll, test, ndx = _setup(fx)
+    e0, t0 = enroll.stat1.copy(), test.stat1.copy()
+    m = iv_scoring.mahalanobis_scoring(enroll, test, ndx, fx["maha_M"])
+    assert m.scoremat.dtype == numpy.float64 and list(m.modelset) == list(fx["cos_modelset"]) and list(m.segset) == list(fx["cos_segset"])
+    assert numpy.array_equal(m.scoremask, fx["plda_scoremask"])
+    numpy.testing.assert_allclose(m.scoremat, fx["maha_scoremat"], rtol=1e-11, atol=1e-9)
+    t = iv_scoring.two_covariance_scoring(enroll, test, ndx, fx["twocov_W"], fx["twocov_B"])
+    numpy.testing.assert_allclose(t.scoremat, fx["twocov_scoremat"], rtol=1e-10, atol=1e-8)
+    assert numpy.array_equal(enroll.stat1, e0) and numpy.array_equal(test.stat1, t0)       # the caller's servers are left alone
+    # against the oracle's per-model loops on a larger ragged problem, asymmetric M included (only sym(M) matters to the score)
+    rs = numpy.random.RandomState(5)
+    E, T, M = rs.randn(301, 96), rs.randn(517, 96), rs.randn(96, 96)
+    ms = 0.5 * (M + M.T)
+    got = iv_scoring.plda_matrix(E, T, -ms, ms, 0.0, 1.0, None)
+    numpy.testing.assert_allclose(got, osc.mahalanobis_scores(E, T, M), rtol=1e-11, atol=1e-10)
+    with pytest.raises(AssertionError, match="dimension mismatch"):
+        iv_scoring.mahalanobis_scoring(enroll, test, ndx, fx["maha_M"][:-1, :-1])
+
+
 def test_million_trial_matrix_and_eer(gpu):
     """BASELINE config 5 sized: 1000 x 1000 trials, D = 256, synthetic speakers; scores vs the oracle, EER +-0.05 %."""
     rs = numpy.random.RandomState(0)

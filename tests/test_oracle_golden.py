@@ -94,6 +94,8 @@ def test_scoring_oracle_matches_reference(golden_dir):
     numpy.testing.assert_allclose(osc.cosine_scores(Ea.dot(fx["wccn"]), Ta.dot(fx["wccn"])), fx["cos_wccn_scoremat"], atol=1e-6)
     mu, F, G, Sigma = fx["mu"], fx["F"], fx["G"], fx["Sigma"]
     numpy.testing.assert_allclose(osc.fast_plda_scores(Ea, Ta, mu, F, Sigma), fx["plda_scoremat"], rtol=1e-9, atol=1e-9)
+    numpy.testing.assert_allclose(osc.mahalanobis_scores(Ea, Ta, fx["maha_M"]), fx["maha_scoremat"], rtol=1e-10, atol=1e-9)
+    numpy.testing.assert_allclose(osc.two_covariance_scores(Ea, Ta, fx["twocov_W"], fx["twocov_B"]), fx["twocov_scoremat"], rtol=1e-9, atol=1e-8)
     numpy.testing.assert_allclose(osc.fast_plda_scores(Ea, Ta, mu, F, Sigma, scaling_factor=0.7), fx["plda_scaled_scoremat"], rtol=1e-9, atol=1e-9)
     numpy.testing.assert_allclose(osc.fast_plda_scores(Ea, Ta, mu, F, Sigma, p_known=0.3), fx["plda_open_scoremat"], rtol=1e-9, atol=1e-9)
     numpy.testing.assert_allclose(osc.full_plda_scores(Ea, Ta, mu, F, G, Sigma), fx["plda_full_scoremat"], rtol=1e-9, atol=1e-9)

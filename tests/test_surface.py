@@ -10,6 +10,8 @@ SURFACE = {
                    "PLDA_scoring": ["enroll", "test", "ndx", "mu", "F", "G", "Sigma", "test_uncertainty", "Vtrans", "p_known", "scaling_factor", "full_model"],
                    "fast_PLDA_scoring": ["enroll", "test", "ndx", "mu", "F", "Sigma", "test_uncertainty", "Vtrans", "p_known", "scaling_factor", "check_missing"],
                    "full_PLDA_scoring": ["enroll", "test", "ndx", "mu", "F", "G", "Sigma", "p_known", "scaling_factor"],
+                   "mahalanobis_scoring": ["enroll", "test", "ndx", "m", "check_missing"],
+                   "two_covariance_scoring": ["enroll", "test", "ndx", "W", "B", "check_missing"],
                    "cosine_matrix": None, "cosine_matrix_device": None, "plda_matrix": None, "plda_matrix_device": None,
                    "cosine_histograms": None, "plda_parameters": None},
     "score_normalization": {"asnorm": ["enrol_xv", "cohort_xv", "ndx"]},
