@@ -88,7 +88,7 @@ template <class LA>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) float As[BM * LDT];
   __shared__ __attribute__((aligned(16))) float Ws[BN * LDT];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
   const int wm = wave >> 1, wn = wave & 1;
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
@@ -172,7 +172,7 @@ template <bool SLICED>
 __global__ __launch_bounds__(256, 2) void gemm128_kernel(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) float As[BM2 * LDT];
   __shared__ __attribute__((aligned(16))) float Ws[BN2 * LDT];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
   const int wm = wave >> 1, wn = wave & 1;
   const int m0 = blockIdx.x * BM2, n0 = blockIdx.y * BN2;
@@ -286,7 +286,7 @@ constexpr int BKH = 64, LDH = BKH * 2 + 16;
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) unsigned char As[BM * LDH];
   __shared__ __attribute__((aligned(16))) unsigned char Ws[BN * LDH];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
   const int wm = wave >> 1, wn = wave & 1;
   // 1-D grid: the NT column tiles of one row tile sit 8 block ids apart -- the same XCD under round-robin dispatch, started together --

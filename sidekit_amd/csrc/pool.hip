@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256, 4) void att_fused_kernel(const uint16_t* __res
                                                         const float* __restrict__ b2, long ld, int D, RowSpan rs, float* __restrict__ out) {
   __shared__ __attribute__((aligned(16))) unsigned char Hs[64 * AF_LD];
   __shared__ __attribute__((aligned(16))) unsigned char Xs[64 * AF_LD];   // the chunk's x[.., 128 columns] (bf16), same row pitch
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, hh = lane >> 5;
   const int b = blockIdx.x, dcol = blockIdx.y * 128 + wave * 32 + r;   // this lane's column
   const long r0 = rs.row0(b);

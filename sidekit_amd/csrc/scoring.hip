@@ -34,7 +34,7 @@ __device__ inline void dgemm_tile(const double* __restrict__ A, const double* __
                                   double* As, double* Bs, f64x4 (&acc)[WT][WT]) {
   constexpr int T = 32 * WT;            // workgroup tile edge
   constexpr int PA = T * DK / 2 / 256;  // double pairs per thread and operand
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1, lr = lane & 15, lk = lane >> 4;
   const bool vec_a = (K & 1) == 0 && (reinterpret_cast<size_t>(A) & 15) == 0;
   const bool vec_b = ((B_KN ? N : K) & 1) == 0 && (reinterpret_cast<size_t>(B) & 15) == 0;
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256, WT == 4 ? 2 : 4) void dgemm_nt_kernel(const do
   constexpr int T = 32 * WT;
   __shared__ __attribute__((aligned(16))) double As[T * DLD];
   __shared__ __attribute__((aligned(16))) double Bs[T * DLD];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wave >> 1, wn = wave & 1, lr = lane & 15, lk = lane >> 4;
   const int m0 = blockIdx.y * T, n0 = blockIdx.x * T;
   f64x4 acc[WT][WT];
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256) void plda_prep_kernel(const double* __restrict
   const double* X = is_t ? Tm : E;
   const int M = is_t ? Nt : Ne;
   const int m0 = (is_t ? (int)blockIdx.y - etiles : (int)blockIdx.y) * T, p = psi ? (int)blockIdx.x - ctiles : (int)blockIdx.x, n0 = p * T;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wave >> 1, wn = wave & 1, lr = lane & 15, lk = lane >> 4;
   f64x4 acc[WT][WT];
   dgemm_tile<WT, true>(X, psi ? Psi : Phi, M, D, D, m0, n0, As, Bs, acc);
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(HTHREADS) void cosine_hist_kernel(const float* __re
   __shared__ unsigned hist[2 * HB];
   __shared__ __attribute__((aligned(16))) float Es[HT * HLD];
   __shared__ __attribute__((aligned(16))) float Ts[HT * HLD];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5, wm = wave >> 2, wn = wave & 3;
   for (int i = tid; i < 2 * HB; i += HTHREADS) hist[i] = 0u;
   const long tiles_n = (Nt + HT - 1) / HT, ntiles = (long)((Ne + HT - 1) / HT) * tiles_n;
