@@ -183,3 +183,54 @@ def m16_dense(W, TH, MT16, K, perm):
                     cyc = read_cycles(addrs)
                     tot += cyc; n += 1; worst = max(worst, cyc)
     return tot / n, worst
+
+
+# ---- stride-2 shapes on a PLANAR image with block lane orders (round 3) -----------------------------------------------------------
+def s2_grid_conflicts(W, TH, CB, MW, WM, GR, GC, key, verbose=False):
+    """Stride-2 3x3 conv, 32x32x16 MFMA (a lane = one output position, 16-B chunk 2 ks + h): staged row = [even columns | odd columns |
+    zero position], lanes of read group g of M-tile i own the GR x GC block at block row wm, block column 2 i + g of the output tile.
+    key(staged row, planar position) -> XOR on the chunk index.  Returns mean / worst LDS cycles per ds_read_b128 (ideal 4)."""
+    WOUT, SPP, KS = W // 2, CB // 16, CB // 32
+    RS = (W + 1) * CB
+    NBC = WOUT // GC
+    assert WOUT % GC == 0 and TH == WM * GR
+    def planar(col):                      # column -1 and column W: the row's trailing zero position
+        if col < 0 or col >= W:
+            return W
+        return (col & 1) * (W // 2) + (col >> 1)
+    def jrel(r):
+        g = 1 if (4 <= r < 12 or 16 <= r < 20 or r >= 28) else 0
+        j = r - (0 if r < 4 else 4 if r < 12 else 8 if r < 20 else 12 if r < 28 else 16)
+        return g, j
+    total = reads = worst = 0
+    for wm in range(WM):
+        for i in range(MW):
+            for dh in range(3):
+                for dw in range(3):
+                    for ks in range(KS):
+                        addrs = []
+                        for lane in range(64):
+                            r, h = lane & 31, lane >> 5
+                            g, j = jrel(r)
+                            bc = min(2 * i + g, NBC - 1)
+                            ho, wo = wm * GR + j // GC, bc * GC + j % GC
+                            row, P = 2 * ho + dh, planar(2 * wo + dw - 1)
+                            c = 2 * ks + h
+                            addrs.append(row * RS + P * CB + (((c ^ key(row, P)) & (SPP - 1)) << 4))
+                        cyc = read_cycles(addrs)
+                        total += cyc; reads += 1; worst = max(worst, cyc)
+    return total / reads, worst
+
+
+def s2_report():
+    # (W, TH, CB, MW, WM, GR, GC): L2A 32->64 ch W 80 (64-B positions), L3A 64->128 W 40, L4A 128->256 W 20 in 64-channel chunks (128 B)
+    shapes = {"L2A": (80, 4, 64, 3, 2, 2, 8), "L3A": (40, 4, 128, 3, 1, 4, 4), "L4A": (20, 8, 128, 3, 1, 8, 2)}
+    for name, (W, TH, CB, MW, WM, GR, GC) in shapes.items():
+        SPP = CB // 16
+        if SPP == 4:    # 4 positions per bank row: P mod 4 picks the quarter, the 2-bit key = (row pair bit, (P >> 2) & 1)
+            key = lambda row, P: ((((row >> 1) & 1) << 1) | ((P >> 2) & 1))
+        elif GC == 4:   # 2 positions per bank row: P & 1 picks the half, 3-bit key = (row pair & 3, (P >> 1) & 1)
+            key = lambda row, P: ((((row >> 1) & 3) << 1) | ((P >> 1) & 1))
+        else:           # 8 x 2 blocks: the two columns are the two halves, 3-bit key = row pair & 7
+            key = lambda row, P: (row >> 1) & 7
+        print(name, "planar image, %d x %d blocks: mean cycles/read %.2f, worst %d" % ((GR, GC) + s2_grid_conflicts(W, TH, CB, MW, WM, GR, GC, key)))

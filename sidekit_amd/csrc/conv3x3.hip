@@ -38,7 +38,7 @@ template <> __device__ inline void mma_step<float>(f32x16& acc, const uint4& w, 
 }
 
 enum { LANES_LINEAR = 0, LANES_GRID = 1, LANES_DENSE = 2 };
-template <typename T_, int CIN_, int COUT_, int S_, int WIN_, int TH_, int WM_, int WN_, int MW_, int NW_, int CK_, int TAPS_, int OCC_ = 0, int PD_ = 0, bool SWZ_ = false, int BLK_ = LANES_LINEAR, bool M16_ = false, bool DIRECT_ = false>
+template <typename T_, int CIN_, int COUT_, int S_, int WIN_, int TH_, int WM_, int WN_, int MW_, int NW_, int CK_, int TAPS_, int OCC_ = 0, int PD_ = 0, bool SWZ_ = false, int BLK_ = LANES_LINEAR, bool M16_ = false, bool DIRECT_ = false, bool S2G_ = false>
 struct ConvCfg {
   // DIRECT: the epilogue stores straight from the accumulators (32x32 MFMA layouts).  A lane holds, for its position, four groups of 4
   // consecutive output channels (8 B of bf16); v_permlane32_swap pairs the groups of lanes r and r + 32 into 16-B pieces of 8
@@ -111,7 +111,26 @@ struct ConvCfg {
   // swizzle key of the staged position (staged row, column): XORed into the 16-B chunk index of the position
   static constexpr int KCMASK = (GC >> SWSH) - 1;                   // GRID: column bits of the key, (col >> SWSH) & KCMASK
   static constexpr int KRSH = SWSH == 0 ? (GC == 4 ? 2 : (GC == 8 ? 3 : 4)) : (SWSH == 1 ? (GC == 8 ? 2 : 3) : 2);   // log2(GC) - SWSH
-  __host__ __device__ static constexpr int swz_key(int row, int col) {
+  // S2G (round 3; A/B shapes X17-X19 only -- measured, not faster, see the shape list): the stride-2 first convolution of a layer on a
+  // PLANAR image with a block lane order.  A tap of a stride-2 convolution
+  // reads every other staged column, so on the row-major image its lanes only ever touch half of the 16-B slots of a bank row (rocprofv3:
+  // 48 / 58 / 70 % of the LDS cycles of layers 2 / 3 / 4 were conflict cycles; scripts/lds_conflicts.py: 7.8 / 10 / 14 cycles per read).
+  // Staged row = [even columns | odd columns | zero position] (a DMA lane may fetch any global address, so the permutation is free): a
+  // tap's lanes then read CONSECUTIVE positions of one plane, and the 16 lanes of read group g of M-tile i own the S2GR x S2GC block at
+  // block row wm, block column 2 i + g of the output tile (2 x 8 at W_out 40, 4 x 4 at 20, 8 x 2 at 10).  Key = (output-row bits, the
+  // position bits above the bank row): 16 different slots under every tap, 4.2 cycles per read in the model (the zero position is the rest).
+  static constexpr bool S2G = S2G_;
+  static constexpr int S2GR = S2G_ ? TH_ / WM_ : 1, S2GC = 16 / S2GR, S2NBC = (WIN_ / S_) / S2GC;
+  static constexpr int S2PPB = 256 / (CK_ * elem<T_>::bytes) > 0 ? 256 / (CK_ * elem<T_>::bytes) : 1;   // positions per 256-B bank row
+  static constexpr int S2PB = S2GC / S2PPB > 0 ? S2GC / S2PPB : 1;                                         // key values taken from the position
+  static_assert(!S2G_ || (BLK_ == LANES_LINEAR && SWZ_ && S_ == 2 && TAPS_ == 9 && !M16_ && TH_ % WM_ == 0 && S2GR * S2GC == 16 &&
+                          (WIN_ / 2) % S2GC == 0 && 2 * MW_ >= S2NBC && S2GC >= S2PPB && S2GR * S2PB == CK_ * elem<T_>::bytes / 16),
+                "S2G: stride 2, swizzled image, 16-position blocks that tile the output rows, one key value per slot of a position");
+  __host__ __device__ static constexpr int planar(int col) { return (col < 0 || col >= WIN) ? WIN : (col & 1) * (WIN / 2) + (col >> 1); }
+  __host__ __device__ static constexpr int unplanar(int P) { return P < WIN / 2 ? 2 * P : 2 * (P - WIN / 2) + 1; }   // P < WIN
+  __host__ __device__ static constexpr int s2_rowkey(int row) { return ((row >> 1) & (S2GR - 1)) * S2PB; }
+  __host__ __device__ static constexpr int swz_key(int row, int col) {   // (staged row, staged position)
+    if (S2G) return s2_rowkey(row) | ((col / S2PPB) & (S2PB - 1));
     if (BLK == LANES_GRID) return (((row & (GR - 1)) << KRSH) | ((col >> SWSH) & KCMASK)) & (SWF - 1);
     if (BLK == LANES_DENSE) return dense_key((row * (WIN + 1) + col) & 15);
     return (col >> SWSH) & (SWF - 1);
@@ -165,6 +184,11 @@ struct ConvCfg {
     } else if constexpr (BLK == LANES_DENSE) {
       const int L = i * 32 + r, row = L / (WIN + 1), col = L % (WIN + 1);
       return (col < WIN && row < TH) ? row * WOUT + col : MT;
+    } else if constexpr (S2G) {
+      const int g = ((r >= 4 && r < 12) || (r >= 16 && r < 20) || r >= 28) ? 1 : 0;
+      const int j = r - (r < 4 ? 0 : (r < 12 ? 4 : (r < 20 ? 8 : (r < 28 ? 12 : 16))));
+      const int bc = 2 * i + g;
+      return bc < S2NBC ? (wm * S2GR + j / S2GC) * WOUT + bc * S2GC + j % S2GC : MT;
     } else {
       return (wm * MW + i) * 32 + r;
     }
@@ -242,8 +266,25 @@ void conv3x3_kernel(ConvArgs a) {
       for (int dw = 0; dw < 3; ++dw) tapreg[t][dw] = lanebase + ((C::swz_key(row0 + t, col0 + dw - 1) ^ h) << 4);
     if constexpr (!C::LEAD) fixreg = col0 == 0 ? C::RS - C::CB : -C::CB;
   }
+  int s2x = 0;   // S2G: taps of the third kernel row read the next output row's staged pair -> another row key: one XOR on the address
+  if constexpr (C::S2G) {
+    const int g = ((r >= 4 && r < 12) || (r >= 16 && r < 20) || r >= 28) ? 1 : 0;
+    const int j = r - (r < 4 ? 0 : (r < 12 ? 4 : (r < 20 ? 8 : (r < 28 ? 12 : 16))));
+    const int ho = wm * C::S2GR + j / C::S2GC;
+    s2x = (C::s2_rowkey(2 * ho) ^ C::s2_rowkey(2 * ho + 2)) << 4;
 #pragma unroll
-  for (int i = 0; i < (C::BLK ? 0 : C::MW); ++i) {
+    for (int i = 0; i < C::MW; ++i) {
+      const int bc = 2 * i + g < C::S2NBC ? 2 * i + g : C::S2NBC - 1;   // lanes past the last block re-read it (and store nothing)
+      const int wo = bc * C::S2GC + j % C::S2GC;
+#pragma unroll
+      for (int dw = 0; dw < 3; ++dw) {
+        const int P = C::planar(2 * wo + dw - 1);
+        base[i][dw] = (2 * ho) * C::RS + P * C::CB + ((h ^ C::swz_key(2 * ho, P)) << 4);
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < ((C::BLK || C::S2G) ? 0 : C::MW); ++i) {
     const int mraw = (wm * C::MW + i) * 32 + r, m = (C::PARTIAL_M && mraw >= C::MT) ? C::MT - 1 : mraw;
     const int ho = m / C::WOUT, wo = m % C::WOUT;
     if constexpr (C::SWZ) {
@@ -365,9 +406,9 @@ void conv3x3_kernel(ConvArgs a) {
       const int slot = q * 64 + lane;
       const unsigned char* src = reinterpret_cast<const unsigned char*>(a.zeros);
       if constexpr (C::SWZ) {
-        const int col = slot / C::SPP, cs = slot % C::SPP;
+        const int col = slot / C::SPP, cs = slot % C::SPP;     // staged position, slot inside it
         const int cc = cs ^ C::swz_key(row, col);
-        if (rowok) src = rowbase + col * (C::CIN * C::EB) + cc * 16;
+        if (rowok) src = rowbase + (C::S2G ? C::unplanar(col) : col) * (C::CIN * C::EB) + cc * 16;
         if ((C::WIN * C::SPP) % 64 == 0 || slot < C::WIN * C::SPP)  // a partial last piece must not run into the next row
           __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                            (__attribute__((address_space(3))) void*)(smem + C::IMG0 + row * C::RS + q * 1024), 16, 0, 0);
@@ -404,7 +445,8 @@ void conv3x3_kernel(ConvArgs a) {
           if (!C::LEAD && dw == 0 && i == 0) return smem + (v + fixreg) + dh * C::RS;
           return smem + v + (C::IMG0 + (i * C::GC + dw - 1) * C::CB + dh * C::RS);
         }
-      } else if constexpr (C::SWZ) return smem + (base[i][tap % 3] ^ (ks << 5)) + (tap / 3) * C::RS;
+      } else if constexpr (C::S2G) return smem + (base[i][tap % 3] ^ ((ks << 5) ^ (tap / 3 == 2 ? s2x : 0))) + (tap / 3) * C::RS;
+      else if constexpr (C::SWZ) return smem + (base[i][tap % 3] ^ (ks << 5)) + (tap / 3) * C::RS;
       else return smem + base[i][0] + (tap / 3) * C::RS + (tap % 3) * C::PSTRIDE + ks * 32;
     };
     if constexpr (C::M16) {
@@ -1007,11 +1049,14 @@ using B_X13  = ConvCfg<bf16_t, 128, 256, 2, 20,  4, 1, 4, 2, 1, 64, 9, 3, 0, tru
 using B_X14  = ConvCfg<bf16_t,  64, 128, 2, 40,  2, 1, 4, 2, 1, 64, 9, 3, 0, true>;     // L3A in 2-row tiles (26 KB), three workgroups per CU
 using B_X15  = ConvCfg<bf16_t, 128, 256, 2, 20,  4, 1, 4, 2, 1, 64, 9, 4, 0, true>;     // L4A in 4-row tiles, four workgroups per CU
 using B_X16  = ConvCfg<bf16_t,  64, 128, 2, 40,  2, 1, 4, 2, 1, 64, 9, 4, 0, true>;     // L3A in 2-row tiles, four workgroups per CU
+using B_X17  = ConvCfg<bf16_t,  32,  64, 2, 80,  4, 2, 2, 3, 1, 32, 9, 2, 0, true, LANES_LINEAR, false, false, true>;    // L2A on the planar image, 2 x 8 blocks: 4.2 instead of 7.8 LDS cycles per read, 179 vs 161 us (64-B positions: the DMA fetches half lines)
+using B_X18  = ConvCfg<bf16_t,  64, 128, 2, 40,  4, 1, 4, 3, 1, 64, 9, 2, 0, true, LANES_LINEAR, false, false, true>;    // L3A on the planar image, 4 x 4 blocks: 4.2 instead of 10 cycles per read, k-loop 6.5 -> 6.3 k cycles, epilogue 2.8 -> 3.4 k: 105 vs 98 us
+using B_X19  = ConvCfg<bf16_t, 128, 256, 2, 20,  8, 1, 4, 3, 1, 64, 9, 2, 0, true, LANES_LINEAR, false, false, true>;    // L4A on the planar image, 8 x 2 blocks: 4.2 instead of 14 cycles per read, 121 vs 128 us alone, 6.07 vs 6.05 ms in the forward
 using F_X0 = ConvCfg<float,  32,  32, 1, 80,  8, 4, 1, 5, 1, 32, 9>;
 using F_X1 = ConvCfg<float,  64,  64, 1, 40,  8, 2, 2, 5, 1, 64, 9>;
 using F_X2 = ConvCfg<float, 128, 128, 1, 20,  8, 1, 4, 5, 1, 128, 9>;
 using F_X3 = ConvCfg<float, 256, 256, 1, 10, 16, 1, 4, 5, 2, 128, 9>;
-using F_X4 = F_X2; using F_X5 = F_X3; using F_X6 = F_X1; using F_X7 = F_X0; using F_X8 = F_X2; using F_X9 = F_X3; using F_X10 = F_X1; using F_X11 = F_X0; using F_X12 = F_X0; using F_X13 = F_X3; using F_X14 = F_X2; using F_X15 = F_X3; using F_X16 = F_X2;
+using F_X4 = F_X2; using F_X5 = F_X3; using F_X6 = F_X1; using F_X7 = F_X0; using F_X8 = F_X2; using F_X9 = F_X3; using F_X10 = F_X1; using F_X11 = F_X0; using F_X12 = F_X0; using F_X13 = F_X3; using F_X14 = F_X2; using F_X15 = F_X3; using F_X16 = F_X2; using F_X17 = F_X1; using F_X18 = F_X2; using F_X19 = F_X3;
 
 using F_L1   = ConvCfg<float,  32,  32, 1, 80,  8, 4, 1, 5, 1, 32, 9, 0, 0, true>;
 using F_L1S  = ConvCfg<float,  32,  32, 1, 80,  8, 4, 1, 5, 1, 32, 1, 0, 0, true>;
@@ -1034,7 +1079,7 @@ static void fill_geom(ConvGeom& g) {
 #define SK_CONV_CASES(X) \
   X(CONV_L1, L1) X(CONV_L1S, L1S) X(CONV_L2A, L2A) X(CONV_L2S, L2S) X(CONV_L2, L2) X(CONV_L3A, L3A) \
   X(CONV_L3S, L3S) X(CONV_L3, L3) X(CONV_L4A, L4A) X(CONV_L4S, L4S) X(CONV_L4, L4) \
-  X(11, X0) X(12, X1) X(13, X2) X(14, X3) X(15, X4) X(16, X5) X(17, X6) X(18, X7) X(19, X8) X(20, X9) X(21, X10) X(22, X11) X(23, X12) X(24, X13) X(25, X14) X(26, X15) X(27, X16)
+  X(11, X0) X(12, X1) X(13, X2) X(14, X3) X(15, X4) X(16, X5) X(17, X6) X(18, X7) X(19, X8) X(20, X9) X(21, X10) X(22, X11) X(23, X12) X(24, X13) X(25, X14) X(26, X15) X(27, X16) X(28, X17) X(29, X18) X(30, X19)
 
 int conv_geom(int shape, int dtype, ConvGeom* g) {
   switch (shape) {
