@@ -278,69 +278,101 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(GemmArgs g) {
     }
 }
 
-// ---- bf16 form: same 64x64 tile, k-tile of 64 bf16, v_mfma_f32_32x32x16_bf16 ------------------------------------
+// ---- bf16 form: 32 x 64 tile, two waves, k-tile of 64 bf16, v_mfma_f32_32x32x16_bf16 ---------------------------------
 // A rows are bf16 already (trunk output) or f32 converted on the way to LDS; W comes pre-converted.  LDS rows are
-// 128 B + 16 B pad (9 slots: conflict-free ds_read_b128).
-constexpr int BKH = 64, LDH = BKH * 2 + 16;
+// 128 B + 16 B pad (9 slots: conflict-free ds_read_b128).  The problems this serves are skinny (attention.0: 13 056 x 128 x 2 560 at
+// B = 256): with 64 x 64 tiles there were 1.6 workgroups per CU, each a chain of 40 k-tiles that waited a full memory latency per tile
+// (45 us, 190 TFLOP/s).  Small tiles (816 workgroups) and operands fetched TWO k-tiles ahead keep several latencies in flight per CU;
+// every output still sums its k in ascending order, so the numbers are those of the 64 x 64 form.
+constexpr int BKH = 64, LDH = BKH * 2 + 16, BMH = 32;
 
-__global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs g) {
-  __shared__ __attribute__((aligned(16))) unsigned char As[BM * LDH];
+template <bool A_BF16>
+__global__ __launch_bounds__(128) void gemm_bf16_kernel(GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) unsigned char As[BMH * LDH];
   __shared__ __attribute__((aligned(16))) unsigned char Ws[BN * LDH];
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tid = threadIdx.x, lane = tid & 63, wn = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
-  const int wm = wave >> 1, wn = wave & 1;
   // 1-D grid: the NT column tiles of one row tile sit 8 block ids apart -- the same XCD under round-robin dispatch, started together --
   // so the second read of the A rows (67 MB for attention.0 at B = 256) is an L2 hit instead of a second trip to HBM
   const int nt_ = (g.N + BN - 1) / BN;
-  const int n0 = (int)((blockIdx.x >> 3) % nt_) * BN, m0 = (int)(((blockIdx.x >> 3) / nt_) * 8 + (blockIdx.x & 7)) * BM;
+  const int n0 = (int)((blockIdx.x >> 3) % nt_) * BN, m0 = (int)(((blockIdx.x >> 3) / nt_) * 8 + (blockIdx.x & 7)) * BMH;
   if (m0 >= g.M) return;
-  // staging: 64 rows x 8 chunks of 8 bf16 -> 512 chunks per operand, 2 per thread
+  // staging: 8 chunks of 8 bf16 per row; 32 A rows -> 2 chunks per thread, 64 W rows -> 4.  The loads carry no guards: rows past M / N
+  // are clamped to the last row (their products land in accumulator rows / columns that are never stored) and K is a whole number of
+  // k-tiles (launch_gemm) -- a guarded load made every wait a vmcnt(0) and the two-tile prefetch below collapsed to one.
   const int srow = tid >> 3, sk8 = (tid & 7) * 8;
-  uint4 ra[2], rw[2];
-  auto fetch = [&](int k0) {
+  constexpr int NA = A_BF16 ? 1 : 2;   // 16-B loads per A chunk
+  const unsigned char* ap[2];
+  const uint16_t* wp[4];
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int row = srow + q * 32, m = m0 + row, n = n0 + row, k = k0 + sk8;
-      uint4 va = make_uint4(0, 0, 0, 0), vw = make_uint4(0, 0, 0, 0);
-      if (m < g.M && k < g.K) {
-        if (g.a_bf16) {
-          va = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(g.A) + (long)m * g.lda + k);
-        } else {
-          const float* p = reinterpret_cast<const float*>(g.A) + (long)m * g.lda + k;
-          const float4 x = *reinterpret_cast<const float4*>(p), y = *reinterpret_cast<const float4*>(p + 4);
-          va = make_uint4(pack_bf16x2(x.x, x.y), pack_bf16x2(x.z, x.w), pack_bf16x2(y.x, y.y), pack_bf16x2(y.z, y.w));
-        }
-      }
-      if (n < g.N && k < g.K) vw = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(g.W_bf16) + (long)n * g.ldw + k);
-      ra[q] = va; rw[q] = vw;
-    }
+  for (int q = 0; q < 2; ++q) {
+    const int m = m0 + srow + q * 16;
+    ap[q] = reinterpret_cast<const unsigned char*>(g.A) + ((long)(m < g.M ? m : g.M - 1) * g.lda + sk8) * (A_BF16 ? 2 : 4);
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int n = n0 + srow + q * 16;
+    wp[q] = reinterpret_cast<const uint16_t*>(g.W_bf16) + (long)(n < g.N ? n : g.N - 1) * g.ldw + sk8;
+  }
+  struct Regs { uint4 a[2][NA]; uint4 w[4]; };   // one k-tile's operands of this thread
+  auto fetch = [&](int k0, Regs& R) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int e = 0; e < NA; ++e) R.a[q][e] = *reinterpret_cast<const uint4*>(ap[q] + (long)k0 * (A_BF16 ? 2 : 4) + e * 16);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) R.w[q] = *reinterpret_cast<const uint4*>(wp[q] + k0);
   };
   f32x16 acc;
 #pragma unroll
   for (int q = 0; q < 16; ++q) acc[q] = 0.f;
-  const int nk = (g.K + BKH - 1) / BKH;
-  fetch(0);
-  for (int kt = 0; kt < nk; ++kt) {
+  const int nk = g.K / BKH;
+  // one k-tile from its registers through LDS to the matrix cores; the registers are refilled with k-tile `next` (always: a loop whose
+  // loads sit behind a condition gets vmcnt(0) waits, and the tile fetched two steps ahead would be waited for at once)
+  auto step = [&](Regs& R, int next) {
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-      *reinterpret_cast<uint4*>(As + (srow + q * 32) * LDH + sk8 * 2) = ra[q];
-      *reinterpret_cast<uint4*>(Ws + (srow + q * 32) * LDH + sk8 * 2) = rw[q];
+      uint4 v;
+      if constexpr (A_BF16) v = R.a[q][0];
+      else {
+        const float4 x = __builtin_bit_cast(float4, R.a[q][0]), y = __builtin_bit_cast(float4, R.a[q][NA - 1]);
+        v = make_uint4(pack_bf16x2(x.x, x.y), pack_bf16x2(x.z, x.w), pack_bf16x2(y.x, y.y), pack_bf16x2(y.z, y.w));
+      }
+      *reinterpret_cast<uint4*>(As + (srow + q * 16) * LDH + sk8 * 2) = v;
     }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) *reinterpret_cast<uint4*>(Ws + (srow + q * 16) * LDH + sk8 * 2) = R.w[q];
     __syncthreads();
-    if (kt + 1 < nk) fetch((kt + 1) * BKH);
+    fetch(next * BKH, R);
 #pragma unroll
     for (int kk = 0; kk < BKH; kk += 16) {
-      const uint4 a = *reinterpret_cast<const uint4*>(As + (wm * 32 + r) * LDH + (kk + 8 * h) * 2);
+      const uint4 a = *reinterpret_cast<const uint4*>(As + r * LDH + (kk + 8 * h) * 2);
       const uint4 b = *reinterpret_cast<const uint4*>(Ws + (wn * 32 + r) * LDH + (kk + 8 * h) * 2);
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
     }
     __syncthreads();
+  };
+  Regs R0, R1;
+  int kt = 0;
+  if (nk & 1) {            // an odd tile count: the first tile on its own, pairs after it
+    fetch(0, R0);
+    step(R0, 0);
+    kt = 1;
+  }
+  const int last = nk - 1;
+  if (kt < nk) {
+    fetch(kt * BKH, R0);
+    fetch((kt + 1) * BKH, R1);
+    for (; kt < nk; kt += 2) {   // tiles past the end are clamped to the last one: fetched again, never used
+      step(R0, kt + 2 < last ? kt + 2 : last);
+      step(R1, kt + 3 < last ? kt + 3 : last);
+    }
   }
   const int n = n0 + wn * 32 + r;
   if (n >= g.N) return;
 #pragma unroll
   for (int q = 0; q < 16; ++q) {
-    const int m = m0 + wm * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+    const int m = m0 + (q & 3) + 8 * (q >> 2) + 4 * h;
     if (m < g.M) g.C[(long)m * g.ldc + n] = gemm_epilogue(g, acc[q], m, n);
   }
 }
@@ -366,8 +398,10 @@ int launch_gemm(const GemmArgs& g_in, hipStream_t s) {
   SK_CHECK(g.M > 0 && g.N > 0 && g.K > 0, SK_EARG, "gemm: empty problem %dx%dx%d", g.M, g.N, g.K);
   SK_CHECK(g.K % 4 == 0 && g.ldw % 4 == 0, SK_EARG, "gemm: K=%d / ldw=%ld must be multiples of 4", g.K, g.ldw);
   SK_CHECK(g.a_mode != A_PLAIN || (g.lda % 4 == 0 && g.kc % 4 == 0), SK_EARG, "gemm: lda/kc alignment");
-  if (g.W_bf16 && g.a_mode == A_PLAIN && g.kc == 0 && g.K % 8 == 0 && g.lda % 8 == 0 && g.ldw % 8 == 0 && g.ksplit == 1) {
-    hipLaunchKernelGGL(gemm_bf16_kernel, dim3((unsigned)(cdiv(cdiv(g.M, BM), 8) * 8 * cdiv(g.N, BN))), dim3(256), 0, s, g);
+  if (g.W_bf16 && g.a_mode == A_PLAIN && g.kc == 0 && g.K % BKH == 0 && g.lda % 8 == 0 && g.ldw % 8 == 0 && g.ksplit == 1) {   // whole k-tiles (the model's two: K = 2560, 128)
+    const dim3 gridh((unsigned)(cdiv(cdiv(g.M, BMH), 8) * 8 * cdiv(g.N, BN)));
+    if (g.a_bf16) hipLaunchKernelGGL(gemm_bf16_kernel<true>, gridh, dim3(128), 0, s, g);
+    else hipLaunchKernelGGL(gemm_bf16_kernel<false>, gridh, dim3(128), 0, s, g);
     SK_HIP(hipGetLastError());
     return SK_OK;
   }
