@@ -481,7 +481,7 @@ void conv3x3_kernel(ConvArgs a) {
         uint4 wf[C::NT16];
 #pragma unroll
         for (int jn = 0; jn < C::NT16; ++jn) wf[jn] = wq16[kk % PD16][jn];
-        if ((u & 1) && kk + PD16 < NK32) {   // the ring slot is free once the step's second half has its fragments
+        if ((u & 1) && kk + PD16 < NK32 && !(a.dbg & 256)) {   // the ring slot is free once the step's second half has its fragments (dbg 256, SIDEKIT_AMD_CONV_DBG: ablation without the refill -- 9-10 % of layers 2 / 3)
 #pragma unroll
           for (int jn = 0; jn < C::NT16; ++jn) wq16[kk % PD16][jn] = wload16(jn, ch * NK32 + kk + PD16);
         }
