@@ -11,6 +11,9 @@ import numpy
 import torch
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from sidekit_amd import _lib   # noqa: E402
+if os.environ.get("SK_LIB"):    # A/B against another build of the library
+    _lib.LIB_PATH = os.path.abspath(os.environ["SK_LIB"])
 from sidekit_amd.nnet.xvector import Xtractor   # noqa: E402
 
 arch = sys.argv[1] if len(sys.argv) > 1 else "halfresnet34"
