@@ -80,72 +80,11 @@ __global__ __launch_bounds__(256) void mean_std_kernel(const void* __restrict__ 
   }
 }
 
-// The same arithmetic with the thread's rows (16 B each) fetched once, all loads in flight together, and both passes run from registers:
-// the row loop above is a chain of dependent L2 / HBM latencies (13 rows x 2 passes at T' = 51: 24 us for 67 MB).  NR * POOL_TG >= the
-// longest utterance of the batch.
-template <int VEC, int NR>
-__global__ __launch_bounds__(256) void mean_std_reg_kernel(const void* __restrict__ x, long ld, int D, RowSpan rs, float* __restrict__ out) {
-  __shared__ float red[POOL_TG][POOL_CG * 8];
-  const int b = blockIdx.x, cg = threadIdx.x % POOL_CG, tg = threadIdx.x / POOL_CG;
-  const int d0 = (blockIdx.y * POOL_CG + cg) * VEC;
-  const bool live = d0 < D;
-  const long r0 = rs.row0(b);
-  const int n = rs.count(b);
-  uint4 raw[NR];
-#pragma unroll
-  for (int i = 0; i < NR; ++i) {
-    const int t = tg + i * POOL_TG;
-    raw[i] = (live && t < n) ? *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(x) + ((r0 + t) * ld + d0) * (16 / VEC)) : make_uint4(0, 0, 0, 0);
-  }
-  auto decode = [&](const uint4& u, float* v) {
-    const uint32_t w[4] = {u.x, u.y, u.z, u.w};
-    if constexpr (VEC == 8) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) { v[2 * q] = bf16_to_f32((uint16_t)(w[q] & 0xffff)); v[2 * q + 1] = bf16_to_f32((uint16_t)(w[q] >> 16)); }
-    } else {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) v[q] = __builtin_bit_cast(float, w[q]);
-    }
-  };
-  float s[VEC], v[VEC], e[VEC];
-#pragma unroll
-  for (int q = 0; q < VEC; ++q) { s[q] = 0.f; v[q] = 0.f; }
-#pragma unroll
-  for (int i = 0; i < NR; ++i) {
-    decode(raw[i], e);
-    if (tg + i * POOL_TG < n) {
-#pragma unroll
-      for (int q = 0; q < VEC; ++q) s[q] += e[q];
-    }
-  }
-  rowgroup_sum<VEC>(red, tg, cg, s);
-#pragma unroll
-  for (int i = 0; i < NR; ++i) {
-    decode(raw[i], e);
-    if (tg + i * POOL_TG < n) {
-#pragma unroll
-      for (int q = 0; q < VEC; ++q) { const float c = e[q] - s[q] / (float)n; v[q] = fmaf(c, c, v[q]); }
-    }
-  }
-  rowgroup_sum<VEC>(red, tg, cg, v);
-  if (live && tg == 0) {
-#pragma unroll
-    for (int q = 0; q < VEC; ++q) {
-      out[(long)b * 2 * D + d0 + q] = s[q] / (float)n;
-      out[(long)b * 2 * D + D + d0 + q] = sqrtf(v[q] / (float)(n - 1));
-    }
-  }
-}
-
 int launch_mean_std(const void* x, int x_bf16, long ld, int D, RowSpan rs, float* out, int B, hipStream_t s) {
   const int VEC = x_bf16 ? 8 : 4;
   SK_CHECK(D % VEC == 0 && ld % VEC == 0, SK_EARG, "mean_std: D=%d, ld=%ld must be multiples of %d", D, ld, VEC);
   const dim3 grid(B, cdiv(D, POOL_CG * VEC));
-  const bool reg = rs.offsets == nullptr && rs.stride > 0 && rs.stride <= 16 * POOL_TG;   // padded layout: an utterance has at most `stride` rows
-  if (reg) {
-    if (x_bf16) hipLaunchKernelGGL((mean_std_reg_kernel<8, 16>), grid, dim3(256), 0, s, x, ld, D, rs, out);
-    else hipLaunchKernelGGL((mean_std_reg_kernel<4, 16>), grid, dim3(256), 0, s, x, ld, D, rs, out);
-  } else if (x_bf16) hipLaunchKernelGGL(mean_std_kernel<8>, grid, dim3(256), 0, s, x, ld, D, rs, out);
+  if (x_bf16) hipLaunchKernelGGL(mean_std_kernel<8>, grid, dim3(256), 0, s, x, ld, D, rs, out);
   else hipLaunchKernelGGL(mean_std_kernel<4>, grid, dim3(256), 0, s, x, ld, D, rs, out);
   SK_HIP(hipGetLastError());
   return SK_OK;

@@ -15,14 +15,21 @@ namespace sk {
 // weights: a thread owns 16 B of consecutive output channels (8 bf16 / 4 f32) and every KG-th (tap, ci) row, so the
 // 9*C*C weights stream as whole 16-B loads (one 2/4-B load per FMA was latency-bound: 55 us at C = 256), partial
 // sums meet in LDS in row-group order; phase 3 is the two small FC layers and the sigmoid.
-template <typename WT>
+constexpr int se_chunk(int nit) {
+  for (int d = 24; d > 1; --d)
+    if (nit % d == 0) return d;
+  return 1;
+}
+
+template <typename WT, int C_>
 __global__ __launch_bounds__(1024) void se_pre_kernel(SeArgs a) {
   constexpr int VEC = 16 / sizeof(WT);
   __shared__ float red[8 * 1024];   // phase 1: 3 x 1024; phase 2: [KG][C] partial sums (KG * C = 1024 * VEC / ... <= 8192)
   __shared__ float S[9 * 256];
   __shared__ float y[256];
   __shared__ float hid[16];
-  const int b = blockIdx.x, C = a.C, G = 1024 / C, c = threadIdx.x % C, g = threadIdx.x / C;
+  constexpr int C = C_, G = 1024 / C;
+  const int b = blockIdx.x, c = threadIdx.x % C, g = threadIdx.x / C;
   const int hb = halve(a.lens.get(b), a.halvings);
   const int nt = (hb + a.th - 1) / a.th;
   float T = 0.f, C0 = 0.f, CL = 0.f;
@@ -51,23 +58,39 @@ __global__ __launch_bounds__(1024) void se_pre_kernel(SeArgs a) {
   }
   __syncthreads();
   {
-    const int CG = C / VEC, KG = 1024 / CG, cg = threadIdx.x % CG, kg = threadIdx.x / CG;
+    constexpr int CG = C / VEC, KG = 1024 / CG;
+    const int cg = threadIdx.x % CG, kg = threadIdx.x / CG;
     float m[VEC];
 #pragma unroll
     for (int v = 0; v < VEC; ++v) m[v] = 0.f;
     const unsigned char* wp = reinterpret_cast<const unsigned char*>(a.w2t) + (size_t)cg * 16;
-#pragma unroll 8
-    for (int k = kg; k < 9 * C; k += KG) {   // k = tap * C + ci; eight 16-B weight loads in flight per thread (the loop is L2-latency bound)
-      const uint4 w = *reinterpret_cast<const uint4*>(wp + (size_t)k * C * sizeof(WT));
-      const float s = S[k];
-      const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+    // k = tap * C + ci, this thread's rows k = kg + i * KG.  The loop is a chain of L2 latencies (72 dependent rounds of one 16-B load at
+    // C = 256 were 55 us, eight in flight 20 us): the trip count is a compile-time constant, so up to 24 loads are issued back to back
+    // (three rounds at C = 256, one at C <= 128) and the FMAs follow in k order -- the sums are those of the rolled loop.
+    constexpr int NIT = (9 * C + KG - 1) / KG, CH = se_chunk(NIT);   // the largest divisor of the trip count up to 24
+#pragma unroll 1
+    for (int i0 = 0; i0 < NIT; i0 += CH) {
+      uint4 w[CH];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        if constexpr (sizeof(WT) == 2) {
-          m[2 * q] = fmaf(bf16_to_f32((uint16_t)(ww[q] & 0xffff)), s, m[2 * q]);
-          m[2 * q + 1] = fmaf(bf16_to_f32((uint16_t)(ww[q] >> 16)), s, m[2 * q + 1]);
-        } else {
-          m[q] = fmaf(__builtin_bit_cast(float, ww[q]), s, m[q]);
+      for (int i = 0; i < CH; ++i) {
+        const int k = kg + (i0 + i) * KG;
+        w[i] = k < 9 * C ? *reinterpret_cast<const uint4*>(wp + (size_t)k * C * sizeof(WT)) : make_uint4(0, 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < CH; ++i) {
+        const int k = kg + (i0 + i) * KG;
+        if (k < 9 * C) {
+          const float s = S[k];
+          const uint32_t ww[4] = {w[i].x, w[i].y, w[i].z, w[i].w};
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            if constexpr (sizeof(WT) == 2) {
+              m[2 * q] = fmaf(bf16_to_f32((uint16_t)(ww[q] & 0xffff)), s, m[2 * q]);
+              m[2 * q + 1] = fmaf(bf16_to_f32((uint16_t)(ww[q] >> 16)), s, m[2 * q + 1]);
+            } else {
+              m[q] = fmaf(__builtin_bit_cast(float, ww[q]), s, m[q]);
+            }
+          }
         }
       }
     }
@@ -115,9 +138,17 @@ __global__ __launch_bounds__(1024) void se_pre_kernel(SeArgs a) {
 }
 
 int launch_se_pre(const SeArgs& a, hipStream_t s) {
-  SK_CHECK(a.C <= 256 && a.C % 16 == 0 && 1024 % a.C == 0, SK_EARG, "se_pre: C=%d unsupported", a.C);
-  if (a.w2t_bf16) hipLaunchKernelGGL(se_pre_kernel<uint16_t>, dim3(a.B), dim3(1024), 0, s, a);
-  else hipLaunchKernelGGL(se_pre_kernel<float>, dim3(a.B), dim3(1024), 0, s, a);
+  SK_CHECK(a.C == 32 || a.C == 64 || a.C == 128 || a.C == 256, SK_EARG, "se_pre: C=%d unsupported (32, 64, 128, 256)", a.C);
+#define SK_SE_LAUNCH(CC) do { \
+    if (a.w2t_bf16) hipLaunchKernelGGL((se_pre_kernel<uint16_t, CC>), dim3(a.B), dim3(1024), 0, s, a); \
+    else hipLaunchKernelGGL((se_pre_kernel<float, CC>), dim3(a.B), dim3(1024), 0, s, a); } while (0)
+  switch (a.C) {
+    case 32: SK_SE_LAUNCH(32); break;
+    case 64: SK_SE_LAUNCH(64); break;
+    case 128: SK_SE_LAUNCH(128); break;
+    default: SK_SE_LAUNCH(256); break;
+  }
+#undef SK_SE_LAUNCH
   SK_HIP(hipGetLastError());
   return SK_OK;
 }
