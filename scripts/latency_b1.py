@@ -3,6 +3,9 @@ call with the queue kept full, and per call when the caller synchronises after e
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+from sidekit_amd import _lib
+if os.environ.get("SK_LIB"):    # A/B against another build of the library
+    _lib.LIB_PATH = os.path.abspath(os.environ["SK_LIB"])
 from sidekit_amd.nnet import Xtractor
 
 dev = torch.device("cuda", 0)
