@@ -481,7 +481,8 @@ void conv3x3_kernel(ConvArgs a) {
         uint4 wf[C::NT16];
 #pragma unroll
         for (int jn = 0; jn < C::NT16; ++jn) wf[jn] = wq16[kk % PD16][jn];
-        if ((u & 1) && kk + PD16 < NK32 && !(a.dbg & 256)) {   // the ring slot is free once the step's second half has its fragments (dbg 256, SIDEKIT_AMD_CONV_DBG: ablation without the refill -- 9-10 % of layers 2 / 3)
+        if ((u & 1) && kk + PD16 < NK32) {   // the ring slot is free once the step's second half has its fragments.  (Round 3 measured this refill at 9-10 % of layers 2 / 3 by
+                                             // switching it off at run time -- and the switch itself, a condition around the loads, cost layers 3 / 4 another 5 %: it is gone.)
 #pragma unroll
           for (int jn = 0; jn < C::NT16; ++jn) wq16[kk % PD16][jn] = wload16(jn, ch * NK32 + kk + PD16);
         }
