@@ -674,11 +674,7 @@ void conv3x3_kernel(ConvArgs a) {
     const unsigned char* scut = reinterpret_cast<const unsigned char*>(a.shortcut);
     // persistent shapes keep 72 registers of weights alive through the epilogue: only the first half of the shortcut
     // chunks is fetched ahead of the epilogue arithmetic, the second half once the accumulators are dead
-#ifdef SK_EXP_NPRE0
-    constexpr int NPRE = 0;
-#else
     constexpr int NPRE = (RESID && C::LEAN) ? (NIT + 1) / 2 : NIT;
-#endif
     uint4 sreg[RESID ? NIT : 1];
     auto fetch_shortcut = [&](int q) {
       const int idx = tid + q * NTHREADS, m = idx / CPR, cc = idx % CPR;
