@@ -666,7 +666,6 @@ void conv3x3_kernel(ConvArgs a) {
   }
 #pragma unroll
   for (int j = 0; j < C::NW; ++j) {
-    __syncthreads();  // every wave is done with the halo tile (j == 0) / the previous sub-tile has been copied out
     const int nbase = (nt0 + j * C::WN + wn) * 32;
     // residual form: this thread's shortcut chunks are fetched now and consumed after the out tile is staged
     constexpr int CPR = NC * C::EB / 16;             // 16-B chunks per position
@@ -685,6 +684,7 @@ void conv3x3_kernel(ConvArgs a) {
 #pragma unroll
       for (int q = 0; q < NPRE; ++q) sreg[q] = fetch_shortcut(q);
     }
+    __syncthreads();  // every wave is done with the halo tile (j == 0) / the previous sub-tile has been copied out; the shortcut loads above are on their way while the wave waits here
     // The 16 accumulator registers of (M-tile i, channel tile j) are four groups g of 4 consecutive output channels:
     //   32x32 MFMA: position lane_pos(i, r), channels 8 g + 4 h .. + 3 of the 32-channel tile;
     //   M16       : quarter g = 2 * (position-tile half) + (channel-tile half): position lane_pos16(2 i + (g >> 1), l & 15),
