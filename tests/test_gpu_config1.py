@@ -236,7 +236,7 @@ def test_install_as_sidekit_runs_reference_style_callers(gpu, ex, tmp_path):
 
 # per-stage relative-error budgets of the bf16 trunk against the fp32 oracle: bf16 rounding (2^-9 per stored value) grows with
 # depth; a stage that breaks its budget localises a defect that the final cosine would wash out
-# measured (scripts/bf16_stage_errors.py, T = 52 .. 801): stem 1.66e-3, layer1 4.4e-3, layer2 5.9e-3, layer3 8.5e-3 .. 9.3e-3, layer4 1.1e-2 .. 1.5e-2
+# measured (tests/tools/bf16_stage_errors.py, T = 52 .. 801): stem 1.66e-3, layer1 4.4e-3, layer2 5.9e-3, layer3 8.5e-3 .. 9.3e-3, layer4 1.1e-2 .. 1.5e-2
 BF16_BUDGET = {"stem": 2.5e-3, "layer1": 7e-3, "layer2": 9e-3, "layer3": 1.4e-2, "layer4": 2.2e-2}
 
 

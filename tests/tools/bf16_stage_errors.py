@@ -1,7 +1,7 @@
 """Measured per-stage relative error of the bf16 trunk against the fp32 oracle (GPU box): the numbers the budgets of
 tests/test_gpu_config1.py::test_bf16_stage_taps_against_the_fp32_oracle are set from."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy, torch
 from oracle import xvector as oxv
 from sidekit_amd.nnet import Xtractor
