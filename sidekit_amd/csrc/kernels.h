@@ -50,9 +50,10 @@ size_t conv_pack_bytes(const ConvGeom& g);
 void conv_pack_weights(const ConvGeom& g, const float* w, int kh_kw, void* dst);
 
 // ---- trunk_misc.hip -----------------------------------------------------------------------
-// stem: features (strides sf, st in elements) -> relu(bn(conv3x3 1->32)) NHWC [B][T][80][32]
-int launch_stem(const float* feats, long sb, long sf, long st, const float* w /*[32][9]*/, const float* scale,
-                const float* shift, void* out, int dtype, Lens lens, int B, int T, hipStream_t s);
+// stem: features (strides sf, st in elements) -> relu(bn(conv3x3 1->32)) NHWC [B][T][80][32]; w = tap-major [9][32] weights with the
+// BatchNorm scale folded in, shift = the BatchNorm shift
+int launch_stem(const float* feats, long sb, long sf, long st, const float* w, const float* shift, void* out, int dtype, Lens lens, int B,
+                int T, hipStream_t s);
 // SE gate of a BasicBlock computed BEFORE its second convolution runs: the plane mean of bn2(conv2(o1)) is linear in
 // o1, so it follows from the sums conv1 left behind (total, first/last row and column, corners) and conv2's weights:
 //   mean[co] = scale2[co] / (H W) * sum_{ci,dh,dw} W2[co][ci][dh][dw] * S[ci][dh][dw] + shift2[co]

@@ -13,8 +13,8 @@ constexpr int STEM_W = 80;
 
 template <int EB>
 __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ feats, long sb, long sf, long st,
-                                                   const float* __restrict__ w, const float* __restrict__ scale,
-                                                   const float* __restrict__ shift, unsigned char* __restrict__ out,
+                                                   const float* __restrict__ w, const float* __restrict__ shift,
+                                                   unsigned char* __restrict__ out,
                                                    Lens lens, int T) {
   __shared__ float patch[(STEM_TT + 2) * (STEM_W + 2)];
   __shared__ __attribute__((aligned(16))) unsigned char stage[256 * (32 * EB + 16)];
@@ -49,14 +49,14 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ fea
         float v[8];
 #pragma unroll
         for (int c = 0; c < 8; c += 2) {   // two channels per v_pk_fma_f32; w is tap-major [9][32], uniform index -> scalar loads
-          f32x2_t s = {0.f, 0.f};
+          f32x2_t s = {shift[c0 + c], shift[c0 + c + 1]};   // w carries the BatchNorm scale (xt_api.hip): bn(conv(x)) = shift + sum w' x
 #pragma unroll
           for (int q = 0; q < 9; ++q) {
             const f32x2_t wq = {w[q * 32 + c0 + c], w[q * 32 + c0 + c + 1]}, xq = {x[q], x[q]};
             s = __builtin_elementwise_fma(wq, xq, s);
           }
-          v[c] = relu_nan(s[0] * scale[c0 + c] + shift[c0 + c]);
-          v[c + 1] = relu_nan(s[1] * scale[c0 + c + 1] + shift[c0 + c + 1]);
+          v[c] = relu_nan(s[0]);
+          v[c + 1] = relu_nan(s[1]);
         }
         if constexpr (EB == 2) {
           *reinterpret_cast<uint4*>(lp + c0 * 2) =
@@ -81,14 +81,14 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ fea
   }
 }
 
-int launch_stem(const float* feats, long sb, long sf, long st, const float* w, const float* scale, const float* shift,
+int launch_stem(const float* feats, long sb, long sf, long st, const float* w, const float* shift,
                 void* out, int dtype, Lens lens, int B, int T, hipStream_t s) {
   const int tiles = cdiv(T, STEM_TT);
   if (dtype == DT_BF16)
-    hipLaunchKernelGGL(stem_kernel<2>, dim3(B * tiles), dim3(256), 0, s, feats, sb, sf, st, w, scale, shift,
+    hipLaunchKernelGGL(stem_kernel<2>, dim3(B * tiles), dim3(256), 0, s, feats, sb, sf, st, w, shift,
                        (unsigned char*)out, lens, T);
   else
-    hipLaunchKernelGGL(stem_kernel<4>, dim3(B * tiles), dim3(256), 0, s, feats, sb, sf, st, w, scale, shift,
+    hipLaunchKernelGGL(stem_kernel<4>, dim3(B * tiles), dim3(256), 0, s, feats, sb, sf, st, w, shift,
                        (unsigned char*)out, lens, T);
   SK_HIP(hipGetLastError());
   return SK_OK;

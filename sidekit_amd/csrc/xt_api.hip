@@ -121,7 +121,7 @@ struct xt_handle {
 
   // halfresnet34
   void* d_zeros = nullptr;
-  float* stem_w = nullptr; float* stem_scale = nullptr; float* stem_shift = nullptr;
+  float* stem_w = nullptr; float* stem_shift = nullptr;   // stem weights carry the BatchNorm scale
   std::vector<Block> blocks;
   float *att_w1x = nullptr, *att_w1c = nullptr, *att_b1 = nullptr, *att_bn_scale = nullptr, *att_bn_shift = nullptr;
   float *att_w2 = nullptr, *att_b2 = nullptr;
@@ -365,16 +365,17 @@ static int finalize_half(xt_handle* h) {
   const std::string sn = "sequence_network";
   std::vector<float> zero64(64, 0.f);  // the zero page the conv staging reads its zero padding from
   SK_TRY(upload(h, zero64.data(), zero64.size() * 4, &h->d_zeros));
-  {  // stem weights tap-major [9][32]: channel pairs are adjacent, which is what the packed-f32 FMAs of stem_kernel want
+  std::vector<float> sc, sh;
+  fold_bn(h, sn + ".bn1", sc, sh);
+  {  // stem weights tap-major [9][32]: channel pairs are adjacent, which is what the packed-f32 FMAs of stem_kernel want.  The BatchNorm
+     // scale is folded into them (f32 weights, f32 arithmetic: one more rounding per weight) and the shift starts the FMA chain, so the
+     // kernel has no separate scale / shift step (64 of its 280 VALU instructions per position)
     const auto& w = T(h, sn + ".conv1.weight");   // [32][1][3][3]
     std::vector<float> wt(9 * 32);
     for (int c = 0; c < 32; ++c)
-      for (int q = 0; q < 9; ++q) wt[q * 32 + c] = w[c * 9 + q];
+      for (int q = 0; q < 9; ++q) wt[q * 32 + c] = w[c * 9 + q] * sc[c];
     SK_TRY(upload_f(h, wt, &h->stem_w));
   }
-  std::vector<float> sc, sh;
-  fold_bn(h, sn + ".bn1", sc, sh);
-  SK_TRY(upload_f(h, sc, &h->stem_scale));
   SK_TRY(upload_f(h, sh, &h->stem_shift));
   static const int first_shape[4] = {CONV_L1, CONV_L2A, CONV_L3A, CONV_L4A};
   static const int rest_shape[4] = {CONV_L1, CONV_L2, CONV_L3, CONV_L4};
@@ -666,7 +667,7 @@ static int half_from_feats(xt_handle* h, Lane& ln, const float* feats, long sb, 
   const size_t act_bytes = (size_t)B * T * 80 * 32 * EB;
   for (int i = 0; i < 4; ++i) SK_CHECK(act_bytes <= ln.ws_act[i].bytes, SK_EWORKSPACE, "activation workspace too small: call xt_reserve(%d, >= %d frames)", B, T);
   void *X = ln.ws_act[0].p, *O1 = ln.ws_act[1].p, *O2 = ln.ws_act[2].p, *SC = ln.ws_act[3].p;
-  { ProfScope ps(h, XT_PROF_STEM, st); SK_TRY(launch_stem(feats, sb, sf, stt, h->stem_w, h->stem_scale, h->stem_shift, X, dt, m.lens, B, T, st)); }
+  { ProfScope ps(h, XT_PROF_STEM, st); SK_TRY(launch_stem(feats, sb, sf, stt, h->stem_w, h->stem_shift, X, dt, m.lens, B, T, st)); }
   SK_TRY(tap(h, "stem", X, act_bytes, st));
   int prev_li = 0;
   for (size_t bi = 0; bi < h->blocks.size(); ++bi) {
