@@ -714,10 +714,9 @@ void conv3x3_kernel(ConvArgs a) {
       float v[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        float x = accv[i][j][4 * g + q] * sc[q] + sh[q];
-        if constexpr (RESID) x *= gt[q];
-        else if (relu) x = relu_nan(x);
-        if constexpr (C::EB == 2) x = round_bf16(x);  // what is stored (and what the next conv reads)
+        float x = fmaf(accv[i][j][4 * g + q], sc[q], sh[q]);   // one rounding (the file is built with -ffp-contract=off); residual form: sc, sh carry the gate
+        if constexpr (!RESID) { if (relu) x = relu_nan(x); }
+        if constexpr (C::EB == 2 && STATS) x = round_bf16(x);  // the plane sums are those of what is stored (the pack below rounds the other forms)
         v[q] = x;
         if constexpr (STATS) ssum[sidx(g) + q] += valid ? x : 0.f;
       }
@@ -847,8 +846,13 @@ void conv3x3_kernel(ConvArgs a) {
           sh_n = ld4(shift, g + 1);
           if constexpr (RESID) gt_n = ld4(gate_b, g + 1);
         }
+        f32x4 sck = sc, shk = sh;
+        if constexpr (RESID) {   // (acc * scale + shift) * gate = acc * (scale * gate) + shift * gate: two products per channel instead of one per value
 #pragma unroll
-        for (int i = 0; i < C::MW; ++i) cell(i, g, sc, sh, gt);
+          for (int q = 0; q < 4; ++q) { sck[q] = sc[q] * gt[q]; shk[q] = sh[q] * gt[q]; }
+        }
+#pragma unroll
+        for (int i = 0; i < C::MW; ++i) cell(i, g, sck, shk, gt);
       }
     } else {
       f32x4 sc[4], sh[4], gt[4];
@@ -857,6 +861,10 @@ void conv3x3_kernel(ConvArgs a) {
         sc[g] = ld4(scale, g);
         sh[g] = ld4(shift, g);
         gt[g] = RESID ? ld4(gate_b, g) : sc[g];
+        if constexpr (RESID) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { sc[g][q] *= gt[g][q]; sh[g][q] *= gt[g][q]; }
+        }
       }
 #pragma unroll
       for (int i = 0; i < C::MW; ++i)
