@@ -716,13 +716,23 @@ void conv3x3_kernel(ConvArgs a) {
       for (int q = 0; q < 4; ++q) {
         float x = fmaf(accv[i][j][4 * g + q], sc[q], sh[q]);   // one rounding (the file is built with -ffp-contract=off); residual form: sc, sh carry the gate
         if constexpr (!RESID) { if (relu) x = relu_nan(x); }
-        if constexpr (C::EB == 2 && STATS) x = round_bf16(x);  // the plane sums are those of what is stored (the pack below rounds the other forms)
         v[q] = x;
-        if constexpr (STATS) ssum[sidx(g) + q] += valid ? x : 0.f;
       }
-      if (store) {
-        if constexpr (C::EB == 2) *reinterpret_cast<uint2*>(lp) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
-        else *reinterpret_cast<float4*>(lp) = make_float4(v[0], v[1], v[2], v[3]);
+      if constexpr (C::EB == 2) {
+        const uint32_t u01 = pack_bf16x2(v[0], v[1]), u23 = pack_bf16x2(v[2], v[3]);   // what is stored (and what the next conv reads)
+        if constexpr (STATS) {   // the plane sums are those of the stored values: widen the packed halves back (one shift / mask each) instead of rounding twice
+          const float r[4] = {__builtin_bit_cast(float, u01 << 16), __builtin_bit_cast(float, u01 & 0xffff0000u),
+                              __builtin_bit_cast(float, u23 << 16), __builtin_bit_cast(float, u23 & 0xffff0000u)};
+#pragma unroll
+          for (int q = 0; q < 4; ++q) ssum[sidx(g) + q] += valid ? r[q] : 0.f;
+        }
+        if (store) *reinterpret_cast<uint2*>(lp) = make_uint2(u01, u23);
+      } else {
+        if constexpr (STATS) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) ssum[sidx(g) + q] += valid ? v[q] : 0.f;
+        }
+        if (store) *reinterpret_cast<float4*>(lp) = make_float4(v[0], v[1], v[2], v[3]);
       }
     };
     if constexpr (RSC) {
