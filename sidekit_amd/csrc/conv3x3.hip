@@ -677,8 +677,13 @@ void conv3x3_kernel(ConvArgs a) {
     // chunks is fetched ahead of the epilogue arithmetic, the second half once the accumulators are dead
     constexpr int NPRE = (RESID && C::LEAN) ? (NIT + 1) / 2 : NIT;
     uint4 sreg[RESID ? NIT : 1];
+    // NC == COUT (every product shape but layer 4's two half-channel workgroups): the tile's rows are one contiguous run of the tensor, chunk
+    // idx sits idx * 16 bytes into it -> wave-uniform base + 32-bit lane offset instead of a 64-bit address per chunk
+    constexpr bool ROWRUN = NC == C::COUT;
+    const size_t run0 = gpos0 * C::COUT * C::EB;
     auto fetch_shortcut = [&](int q) {
       const int idx = tid + q * NTHREADS, m = idx / CPR, cc = idx % CPR;
+      if constexpr (ROWRUN) return (idx < mvalid * CPR) ? *reinterpret_cast<const uint4*>(scut + run0 + (unsigned)idx * 16u) : make_uint4(0, 0, 0, 0);
       return (idx < mvalid * CPR) ? *reinterpret_cast<const uint4*>(scut + ((gpos0 + m) * C::COUT + nt0 * 32 + j * NC) * C::EB + cc * 16)
                                   : make_uint4(0, 0, 0, 0);
     };
@@ -706,9 +711,9 @@ void conv3x3_kernel(ConvArgs a) {
     auto ld4 = [&](const float* p, int g) { return *reinterpret_cast<const f32x4*>(p + nbase + coff(g)); };
     const float* gate_b = (RESID || RSC) ? gate + (size_t)b * C::COUT : scale;
     // one (M-tile i, channel group g) cell: 4 values -> BN, gate or ReLU, rounding, plane sums, 8/16 B into the out tile
-    auto cell = [&](int i, int g, const f32x4& sc, const f32x4& sh, const f32x4& gt) {
+    auto cell = [&](int i, int g, const f32x4& sc, const f32x4& sh, const f32x4& gt, auto full_tag) {
       const int m = pos_of(i, g);
-      const bool valid = m < mvalid;   // mvalid <= MT
+      const bool valid = decltype(full_tag)::value || m < mvalid;   // mvalid <= MT; full tiles (all but an utterance's last) carry no per-value select
       unsigned char* lp = smem + m * OPS + (wn * 32 + coff(g)) * C::EB;
       const bool store = !C::PARTIAL_M || m < C::MT;
       float v[4];
@@ -861,8 +866,13 @@ void conv3x3_kernel(ConvArgs a) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) { sck[q] = sc[q] * gt[q]; shk[q] = sh[q] * gt[q]; }
         }
+        if (STATS && !C::PARTIAL_M && mvalid == C::MT) {   // wave-uniform
 #pragma unroll
-        for (int i = 0; i < C::MW; ++i) cell(i, g, sck, shk, gt);
+          for (int i = 0; i < C::MW; ++i) cell(i, g, sck, shk, gt, FormTag<1>{});
+        } else {
+#pragma unroll
+          for (int i = 0; i < C::MW; ++i) cell(i, g, sck, shk, gt, FormTag<0>{});
+        }
       }
     } else {
       f32x4 sc[4], sh[4], gt[4];
@@ -879,7 +889,7 @@ void conv3x3_kernel(ConvArgs a) {
 #pragma unroll
       for (int i = 0; i < C::MW; ++i)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) cell(i, g, sc[g], sh[g], gt[g]);
+        for (int g = 0; g < 4; ++g) cell(i, g, sc[g], sh[g], gt[g], FormTag<0>{});
     }
     if constexpr (STATS && C::M16) {  // a lane's 8 sums belong to its 16-lane row (one row per 4 output channels of each 16-channel tile)
 #pragma unroll
@@ -954,7 +964,8 @@ void conv3x3_kernel(ConvArgs a) {
             v = __builtin_bit_cast(uint4, make_float4(relu_nan(vf.x + sf.x), relu_nan(vf.y + sf.y), relu_nan(vf.z + sf.z), relu_nan(vf.w + sf.w)));
           }
         }
-        *reinterpret_cast<uint4*>(out + ((gpos0 + m) * C::COUT + nt0 * 32 + j * NC) * C::EB + cc * 16) = v;
+        if constexpr (ROWRUN) *reinterpret_cast<uint4*>(out + run0 + (unsigned)idx * 16u) = v;
+        else *reinterpret_cast<uint4*>(out + ((gpos0 + m) * C::COUT + nt0 * 32 + j * NC) * C::EB + cc * 16) = v;
       }
     }
   }
