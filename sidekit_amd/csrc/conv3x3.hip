@@ -944,20 +944,25 @@ void conv3x3_kernel(ConvArgs a) {
       }
     }
     if (!(a.dbg & 1)) {
+      // chunk idx = tid + q * NTHREADS of the tile: position m = idx / CPR, 16-B piece cc = idx % CPR.  With NTHREADS a multiple of CPR the
+      // lane part (tid / CPR, tid % CPR) is computed once and a step of q is a constant LDS offset (the compiler does not see that through the
+      // signed divisions: seven address instructions per chunk)
+      static_assert(NTHREADS % CPR == 0, "copy-out: whole positions per round");
+      const unsigned lane_lds = ((unsigned)tid / CPR) * OPS + ((unsigned)tid % CPR) * 16;
 #pragma unroll
       for (int q = 0; q < NIT; ++q) {
         const int idx = tid + q * NTHREADS, m = idx / CPR, cc = idx % CPR;
         if (idx >= mvalid * CPR) break;
-        uint4 v = *reinterpret_cast<const uint4*>(smem + m * OPS + cc * 16);
+        uint4 v = *reinterpret_cast<const uint4*>(smem + lane_lds + q * (NTHREADS / CPR) * OPS);
         if constexpr (RESID) {
           const uint4 s = sreg[q];
           if constexpr (C::EB == 2) {
             const uint32_t vv[4] = {v.x, v.y, v.z, v.w}, ss[4] = {s.x, s.y, s.z, s.w};
             uint32_t rr[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-              rr[e] = pack_bf16x2(relu_nan(bf16_to_f32(vv[e] & 0xffff) + bf16_to_f32(ss[e] & 0xffff)),
-                                  relu_nan(bf16_to_f32(vv[e] >> 16) + bf16_to_f32(ss[e] >> 16)));
+            for (int e = 0; e < 4; ++e)   // bf16 halves widened with ONE instruction each (shift for the low half, mask for the high one)
+              rr[e] = pack_bf16x2(relu_nan(__builtin_bit_cast(float, vv[e] << 16) + __builtin_bit_cast(float, ss[e] << 16)),
+                                  relu_nan(__builtin_bit_cast(float, vv[e] & 0xffff0000u) + __builtin_bit_cast(float, ss[e] & 0xffff0000u)));
             v = make_uint4(rr[0], rr[1], rr[2], rr[3]);
           } else {
             const float4 vf = __builtin_bit_cast(float4, v), sf = __builtin_bit_cast(float4, s);
