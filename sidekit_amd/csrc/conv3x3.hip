@@ -720,7 +720,8 @@ void conv3x3_kernel(ConvArgs a) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         float x = fmaf(accv[i][j][4 * g + q], sc[q], sh[q]);   // one rounding (the file is built with -ffp-contract=off); residual form: sc, sh carry the gate
-        if constexpr (!RESID) { if (relu) x = relu_nan(x); }
+        if constexpr (STATS) x = relu_nan(x);   // the statistics form is conv1 + bn1 + ReLU of a block (launch_cfg checks a.relu): no run-time select per value
+        else if constexpr (!RESID) { if (relu) x = relu_nan(x); }
         v[q] = x;
       }
       if constexpr (C::EB == 2) {
@@ -1016,6 +1017,7 @@ static int launch_cfg(const ConvArgs& a, hipStream_t st) {
     fprintf(stderr, "[conv occupancy] LDS %d B, compiled for %d waves/SIMD: %d workgroups per CU\n", C::LDS, C::OCC, nb);
   }
   SK_CHECK(!(a.gate && a.se_part), SK_EARG, "a convolution is either the statistics or the residual form");
+  SK_CHECK(!a.se_part || a.relu, SK_EARG, "the statistics form is conv1 + bn1 + ReLU of a block: relu must be set");
   if constexpr (C::TAPS == 9 && C::NW == 1 && C::S == 2) {
     if (a.sc_wpack) {
       SK_CHECK(a.se_part, SK_EARG, "the fused shortcut belongs to the first convolution of a block (statistics form)");
