@@ -88,6 +88,12 @@ struct Lens {
   const int* frames;  // device, [B] or nullptr
   int uniform;        // used when frames == nullptr
   __device__ inline int get(int b) const { return frames ? frames[b] : uniform; }
+  // the same for a wave-uniform b, through the scalar cache (the array is not written while a kernel runs).  A persistent workgroup that
+  // reads its next tile's length with a VECTOR load waits -- vmcnt(0), stores count on it on gfx9 -- for every store of the tile it has
+  // just finished before it can issue the next tile's DMA.
+  __device__ inline int get_uniform(int b) const {
+    return frames ? *reinterpret_cast<const __attribute__((address_space(4))) int*>((unsigned long long)(frames + b)) : uniform;
+  }
 };
 
 // Sum over each 32-lane half of the wave on the VALU's DPP path (no LDS crossbar traffic, 5 adds): xor-1 and xor-2 inside

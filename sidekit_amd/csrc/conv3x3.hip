@@ -365,7 +365,7 @@ void conv3x3_kernel(ConvArgs a) {
   const int lane = tid & 63, r = lane & 31, h = lane >> 5;
   const int b = work / tiles, tile = work % tiles;
   const int ho0 = tile * C::TH;
-  const int hin_b = __builtin_amdgcn_readfirstlane(halve(a.lens.get(b), a.halvings_in));  // wave-uniform: keep the row bounds in SGPRs
+  const int hin_b = halve(a.lens.get_uniform(b), a.halvings_in);  // scalar load: the row bounds live in SGPRs and the tile does not wait for the previous tile's stores
   const int hout_b = (C::S == 2) ? ((hin_b + 1) >> 1) : hin_b;
   if (ho0 >= hout_b) return false;  // nothing valid in this tile (its SE partial is never read)
   if (!first_item) __syncthreads();  // the previous tile's copy-out has left the LDS
