@@ -158,6 +158,12 @@ int sc_cosine(const float* d_E, int32_t Ne, const float* d_T, int32_t Nt, int32_
 int sc_plda_fast(const double* d_E, int32_t Ne, const double* d_T, int32_t Nt, int32_t D, const double* d_Phi,
                  const double* d_Psi, double cst, double scaling, double* d_out, void* stream);
 
+/* sc_plda_fast keeps its intermediate buffer (E.Psi and the quadratic-form partials) cached per (device, stream) so that a call
+ * allocates nothing; this frees every cached buffer (after a device synchronise).  The Python shim calls it at interpreter exit;
+ * a long-lived host that creates and destroys many streams may call it whenever no sc_plda_fast call is in flight.  The reference
+ * has no counterpart (its temporaries are numpy arrays, sidekit/iv_scoring.py:449-460). */
+int sc_release_workspace(void);
+
 /* All-pairs cosine scoring without the score matrix (100k x 100k trials = 40 GB of float32): the scores of
  * sc_cosine are classified target (labels_e[i] == labels_t[j]) / non-target and counted into two histograms of `nbins`
  * (= 8192) equal bins over [lo, hi) (out-of-range scores land in the end bins); self_offset >= 0 drops the trials

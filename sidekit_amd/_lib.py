@@ -51,6 +51,7 @@ SIGNATURES = {
     "sk_resample": (ctypes.c_int, [_P, _I32, _I64, _I32, _I32, _P, _I64, ctypes.POINTER(_I64), _P]),
     "sc_cosine": (ctypes.c_int, [_P, _I32, _P, _I32, _I32, _P, _P]),
     "sc_plda_fast": (ctypes.c_int, [_P, _I32, _P, _I32, _I32, _P, _P, _F64, _F64, _P, _P]),
+    "sc_release_workspace": (ctypes.c_int, []),
     "sc_cosine_hist": (ctypes.c_int, [_P, _I32, _P, _I32, _I32, _P, _P, _I32, ctypes.c_float, ctypes.c_float, _I32, _P, _P, _P]),
     "sc_cosine_trials": (ctypes.c_int, [_P, _P, _I32, _P, _P, _I64, _P, _P]),
     "sc_topk_stats": (ctypes.c_int, [_P, _I32, _I32, _I32, _P, _P, _P]),
@@ -83,7 +84,19 @@ def lib():
         fn.restype = res
         fn.argtypes = args
     _lib = cdll
+    import atexit
+    atexit.register(_release_at_exit)
     return _lib
+
+
+def _release_at_exit():
+    """Free the scoring workspace cache (scoring.hip); only if this process ever used the GPU."""
+    try:
+        import torch
+        if _lib is not None and torch.cuda.is_initialized():
+            _lib.sc_release_workspace()
+    except Exception:   # interpreter teardown: nothing to report to
+        pass
 
 
 def last_error():

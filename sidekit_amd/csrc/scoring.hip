@@ -420,15 +420,18 @@ __global__ void snorm_apply_kernel(float* __restrict__ S, int ne, int nt, const 
 
 // ---- workspace of sc_plda_fast: E . Psi (Ne x D) and the partial quadratic forms, cached per (device, stream) so that a call
 // allocates nothing in the steady state (three hipMallocAsync / hipFreeAsync pairs per call were most of a 1000 x 1000 scoring).  A
-// stream's calls are ordered, so reuse needs no further synchronisation; growth waits for that stream's earlier calls first.
+// stream's calls are ordered, so reuse needs no further synchronisation; growth waits for that stream's earlier calls first.  The
+// caller holds g_plda_mu from the lookup until its two kernels are enqueued (with the lock dropped in between, a second host
+// thread growing the same stream's entry could free the buffer a first thread was about to launch on).  Entries live until
+// sc_release_workspace() (called by the Python shim at interpreter exit and by tests); a stream handle the runtime recycles finds the
+// old entry, which is harmless for the same reason reuse is: work on one stream handle is ordered.
 struct PldaWs { void* p = nullptr; size_t bytes = 0; };
 static std::mutex g_plda_mu;
 static std::map<std::pair<int, hipStream_t>, PldaWs> g_plda_ws;
 
-static int plda_workspace(hipStream_t st, size_t bytes, void** out) {
+static int plda_workspace_locked(hipStream_t st, size_t bytes, void** out) {
   int dev = 0;
   SK_HIP(hipGetDevice(&dev));
-  std::lock_guard<std::mutex> lock(g_plda_mu);
   PldaWs& w = g_plda_ws[{dev, st}];
   if (bytes > w.bytes) {
     if (w.p) { SK_HIP(hipStreamSynchronize(st)); SK_HIP(hipFree(w.p)); w.p = nullptr; w.bytes = 0; }
@@ -460,7 +463,8 @@ int sc_plda_fast(const double* d_E, int32_t Ne, const double* d_T, int32_t Nt, i
   const int ctiles = cdiv(D, 64);
   const size_t n_epsi = ((size_t)Ne * D + 1) & ~(size_t)1, n_qe = (size_t)ctiles * Ne, n_qt = (size_t)ctiles * Nt;
   void* ws = nullptr;
-  SK_TRY(plda_workspace(st, (n_epsi + n_qe + n_qt) * 8, &ws));
+  std::lock_guard<std::mutex> lock(g_plda_mu);   // held until both launches are enqueued (see plda_workspace_locked)
+  SK_TRY(plda_workspace_locked(st, (n_epsi + n_qe + n_qt) * 8, &ws));
   double* epsi = (double*)ws;
   double* qe = epsi + n_epsi;
   double* qt = qe + n_qe;
@@ -472,6 +476,21 @@ int sc_plda_fast(const double* d_E, int32_t Ne, const double* d_T, int32_t Nt, i
   if (big) hipLaunchKernelGGL(dgemm_nt_kernel<4>, dim3(cdiv(Nt, 128), cdiv(Ne, 128)), dim3(256), 0, st, epsi, d_T, d_out, Ne, Nt, D, qe, qt, ctiles, cst, scaling);
   else hipLaunchKernelGGL(dgemm_nt_kernel<2>, dim3(cdiv(Nt, 64), cdiv(Ne, 64)), dim3(256), 0, st, epsi, d_T, d_out, Ne, Nt, D, qe, qt, ctiles, cst, scaling);
   SK_HIP(hipGetLastError());
+  return SK_OK;
+}
+
+int sc_release_workspace(void) {
+  std::lock_guard<std::mutex> lock(g_plda_mu);
+  int cur = 0;
+  (void)hipGetDevice(&cur);
+  for (auto& kv : g_plda_ws) {
+    if (!kv.second.p) continue;
+    if (hipSetDevice(kv.first.first) != hipSuccess) continue;
+    (void)hipDeviceSynchronize();
+    (void)hipFree(kv.second.p);
+  }
+  g_plda_ws.clear();
+  (void)hipSetDevice(cur);
   return SK_OK;
 }
 

@@ -77,8 +77,13 @@ struct Lane {
   bool ring_used[RING] = {false, false, false, false};
   size_t ring_bytes = 0;
   int ring_cur = 0;
-  hipStream_t stream = nullptr;        // lane 1 only: the stream its half of the batch runs on
+  hipStream_t stream = nullptr;        // lanes 1 .. n-1 only: the stream that part of the batch runs on
   hipEvent_t fork = nullptr, join = nullptr;
+  std::vector<std::pair<int, int64_t>> reserved;   // side lanes: the (utterances, samples) shapes this lane's workspace has been sized for
+  bool covers(int B, int64_t L) const {
+    for (auto& r : reserved) if (r.first >= B && r.second >= L) return true;
+    return false;
+  }
 };
 
 static int lanes_from_env() {
@@ -987,7 +992,10 @@ static int reserve_lane(xt_handle* h, Lane& ln, int32_t max_batch, int64_t max_s
   return SK_OK;
 }
 
-// lanes 1 .. n-1 take the later parts of a split batch (part k of n: rows [k B / n, (k + 1) B / n))
+// lanes 1 .. n-1 take the later parts of a split batch (part k of n': rows [k B / n', (k + 1) B / n')).  A batch SMALLER than the
+// reserved one is split into FEWER, larger parts (lanes = 4, reserve 256: B = 255 gives three parts of 85), so lane k is sized for the
+// largest part it can ever be handed by a batch this shape covers: it runs only when n' >= k + 1, i.e. at most ceil(max_batch / (k + 1))
+// utterances (sizing it for ceil(max_batch / n) let the STFT kernel write past ws_feat on a final partial batch).
 static int reserve_side_lanes(xt_handle* h, int32_t max_batch, int64_t max_samples) {
   if (h->cfg.arch != XT_ARCH_HALFRESNET34) return SK_OK;
   const int n = lane_parts(h->lanes, max_batch, xt_handle::LANE_MIN);
@@ -998,7 +1006,9 @@ static int reserve_side_lanes(xt_handle* h, int32_t max_batch, int64_t max_sampl
       SK_HIP(hipEventCreateWithFlags(&lk.fork, hipEventDisableTiming));
       SK_HIP(hipEventCreateWithFlags(&lk.join, hipEventDisableTiming));
     }
-    SK_TRY(reserve_lane(h, lk, (max_batch + n - 1) / n, max_samples));
+    const int part = (max_batch + k) / (k + 1);
+    SK_TRY(reserve_lane(h, lk, part, max_samples));
+    if (!lk.covers(part, max_samples)) lk.reserved.push_back({part, max_samples});
   }
   return SK_OK;
 }
@@ -1032,8 +1042,9 @@ static int lane_frontend(xt_handle* h, Lane& ln, const void* d_wav, int pcm16, i
                          BatchMeta& m, hipStream_t st) {
   SK_TRY(make_meta(h, ln, h_nsamples, B, L, true, m, st));
   float* feat = (float*)ln.ws_feat.p;
-  SK_TRY(frontend_rows(h, ln, d_wav, pcm16, wav_ld, m, feat, st));
   const int M = m.R ? m.R : m.B * m.T;
+  SK_CHECK((size_t)M * h->fc.n_out * 4 <= ln.ws_feat.bytes, SK_EWORKSPACE, "feature workspace too small for %d x %d frames (xt_reserve)", m.B, m.T);
+  SK_TRY(frontend_rows(h, ln, d_wav, pcm16, wav_ld, m, feat, st));
   return tap(h, "feats", feat, (size_t)M * h->fc.n_out * 4, st);
 }
 
@@ -1050,7 +1061,16 @@ static int forward_wav(xt_handle* h, const void* d_wav, int pcm16, int64_t wav_l
   hipStream_t st = (hipStream_t)stream;
   Lane& l0 = h->lane[0];
   int n = (h->debug || h->cfg.arch != XT_ARCH_HALFRESNET34) ? 1 : lane_parts(h->lanes, B, xt_handle::LANE_MIN);
-  while (n > 1 && !h->lane[n - 1].stream) --n;          // lanes that xt_reserve has not created yet (handle switched after its last reserve)
+  // fewer parts until every side lane exists (a handle switched after its last reserve) and its workspace covers its part: nothing
+  // is enqueued before every part is known to fit
+  auto parts_fit = [&](int np) {
+    for (int k = 1; k < np; ++k) {
+      const int r0 = (int)((long)k * B / np), r1 = (int)((long)(k + 1) * B / np);
+      if (!h->lane[k].stream || !h->lane[k].covers(r1 - r0, L)) return false;
+    }
+    return true;
+  };
+  while (n > 1 && !parts_fit(n)) --n;
   BatchMeta m0;
   if (n == 1) {
     SK_TRY(lane_frontend(h, l0, d_wav, pcm16, wav_ld, h_nsamples, B, L, m0, st));
@@ -1060,25 +1080,36 @@ static int forward_wav(xt_handle* h, const void* d_wav, int pcm16, int64_t wav_l
   // lane starts behind everything queued on the caller's stream so far (its input may still be in flight) and the caller's stream
   // continues only once every part is done.  Round 3 found the first version of this giving a few wrong spectrum bins per batch in
   // the second lane: the STFT kernel's SLP-formed packed-f32 instructions (v_pk_add_f32 / v_pk_mul_f32 with op_sel / neg modifiers)
-  // misbehave on MI355X beside another stream's dense bf16 MFMAs.  The library is built without them now (csrc/Makefile); the
-  // evidence is under profiles/r03_two_lane_frontend_hazard.txt and tests/test_gpu_fullsize.py repeats the split forward against
-  // the serial one.
+  // misbehave on MI355X beside another stream's dense bf16 MFMAs.  The library is built without them now (csrc/Makefile; DESIGN 6;
+  // tests/test_isa_guard.py keeps them out) and tests/test_gpu_fullsize.py repeats the split forward against the serial one.
   const size_t eb = pcm16 ? 2 : 4;
   for (int k = 1; k < n; ++k) {
     SK_HIP(hipEventRecord(h->lane[k].fork, st));
     SK_HIP(hipStreamWaitEvent(h->lane[k].stream, h->lane[k].fork, 0));
   }
-  for (int k = 0; k < n; ++k) {
+  // An error in one part must not leave the others running unjoined: the caller's stream would no longer order behind the side
+  // streams (which keep writing d_emb / d_logits) and the next call would reuse their workspaces.  So every lane that was forked
+  // is joined whatever happened, and the first error is what the call returns.
+  int rc = SK_OK;
+  char first_err[sizeof(g_err)] = "";
+  for (int k = 0; k < n && rc == SK_OK; ++k) {
     Lane& lk = h->lane[k];
     const int r0 = (int)((long)k * B / n), r1 = (int)((long)(k + 1) * B / n);
     hipStream_t sk_ = k ? lk.stream : st;
     BatchMeta mk;
-    SK_TRY(lane_frontend(h, lk, (const unsigned char*)d_wav + (size_t)r0 * wav_ld * eb, pcm16, wav_ld, h_nsamples ? h_nsamples + r0 : nullptr, r1 - r0, L, mk, sk_));
-    SK_TRY(lane_trunk(h, lk, mk, d_emb + (size_t)r0 * h->cfg.emb_dim, d_logits ? d_logits + (size_t)r0 * h->cfg.n_spk : nullptr, sk_));
-    if (k) SK_HIP(hipEventRecord(lk.join, lk.stream));
+    rc = lane_frontend(h, lk, (const unsigned char*)d_wav + (size_t)r0 * wav_ld * eb, pcm16, wav_ld, h_nsamples ? h_nsamples + r0 : nullptr, r1 - r0, L, mk, sk_);
+    if (rc == SK_OK) rc = lane_trunk(h, lk, mk, d_emb + (size_t)r0 * h->cfg.emb_dim, d_logits ? d_logits + (size_t)r0 * h->cfg.n_spk : nullptr, sk_);
+    if (rc != SK_OK) snprintf(first_err, sizeof(first_err), "%s", g_err);
   }
-  for (int k = 1; k < n; ++k) SK_HIP(hipStreamWaitEvent(st, h->lane[k].join, 0));
-  return SK_OK;
+  for (int k = 1; k < n; ++k) {
+    const bool joined = hipEventRecord(h->lane[k].join, h->lane[k].stream) == hipSuccess && hipStreamWaitEvent(st, h->lane[k].join, 0) == hipSuccess;
+    if (!joined) {   // last resort: drain the side stream on the host
+      (void)hipStreamSynchronize(h->lane[k].stream);
+      if (rc == SK_OK) { rc = SK_EHIP; snprintf(first_err, sizeof(first_err), "xt_forward: joining lane %d failed", k); }
+    }
+  }
+  if (rc != SK_OK) set_error("%s", first_err);
+  return rc;
 }
 
 int xt_forward(xt_handle* h, const float* d_wav, int64_t wav_ld, const int32_t* h_nsamples, int32_t B, int64_t L, float* d_emb,
