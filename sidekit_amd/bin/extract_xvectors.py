@@ -109,7 +109,8 @@ def main(xtractor, wav_scp, out_file, device, sample_rate=16000, out_file_spk=""
     stream = StreamingExtractor(xtractor, batch_size=batch_size, window=window, workers=workers, sample_rate=sample_rate)
     results = stream.run((key, ' '.join(utt2wav[key])) for key in keys[lo:hi])
     out_ark = os.path.realpath(os.path.join(os.path.dirname(out_file), os.path.splitext(os.path.basename(out_file))[0]))
-    if world == 1:
+    sharded = dist.is_initialized()   # under torch.distributed.run, also with ONE rank: the RCCL gather path is the one that runs
+    if not sharded:
         # one process: every x-vector goes to the ark as its batch comes back (the reference writes per utterance, :147), the scp
         # grows beside it in arrival order (flushed per batch: what was extracted survives an interruption) and is rewritten in
         # wav.scp order at the end
@@ -123,8 +124,8 @@ def main(xtractor, wav_scp, out_file, device, sample_rate=16000, out_file_spk=""
             for key in utt2wav:
                 f.write(lines[key])
         vecs = None
-    mine = dict(results) if world > 1 else None
-    if world > 1:
+    mine = dict(results) if sharded else None
+    if sharded:
         dev = torch.device(xtractor.device)
         block = numpy.concatenate([mine[k] for k in keys[lo:hi]]) if hi > lo else numpy.zeros((0, xtractor.embedding_size), dtype=numpy.float32)
         full = gather_xvectors(torch.from_numpy(numpy.ascontiguousarray(block, dtype=numpy.float32)).to(dev)).cpu().numpy()
@@ -173,7 +174,7 @@ def cli(argv=None):
         assert os.path.isdir(os.path.dirname(args.out_spk_scp)), "NO SUCH DIRECTORY: %s" % args.out_spk_scp
         assert os.path.isfile(args.spk2utt_file), "NO SUCH FILE: %s" % args.spk2utt_file
     device = args.device.strip().lower()
-    if "RANK" in os.environ and int(os.environ.get("WORLD_SIZE", "1")) > 1:   # python -m torch.distributed.run --nproc-per-node N -m sidekit_amd.bin.extract_xvectors ...
+    if "RANK" in os.environ:   # python -m torch.distributed.run --nproc-per-node N -m sidekit_amd.bin.extract_xvectors ...
         local = int(os.environ.get("LOCAL_RANK", "0"))
         if device.startswith("cuda"):
             os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")

@@ -142,6 +142,9 @@ def main(argv=None, model=None, scoring=None):
     sync()
     t_gather = time.perf_counter() - t0
     assert xv.shape == (N, model.embedding_size) and xv.device.type == dev.type
+    norms = xv.double().norm(dim=1)
+    a0, b0 = shard_range(N, rank, world)
+    gathered_own_block_ok = bool(torch.equal(xv[a0:b0], local_xv))     # the gather put this rank's block where the index range says
     # ---- the gathered x-vectors' own trial set: enrol [0, n), test [n, 2n), PLDA training on the rest
     n = args.trials
     E, T, train = xv[:n], xv[n:2 * n], xv[2 * n:]
@@ -164,7 +167,9 @@ def main(argv=None, model=None, scoring=None):
     t_plda = time.perf_counter() - t0
     out = {"ranks": world, "utterances": N, "x_vectors_per_s": N / t_extract, "extract_s": t_extract, "all_gather_s": t_gather,
            "trials": n * n, "cosine_score_s": t_cos, "plda_score_s": t_plda, "dtype": args.dtype,
-           "plda": args.plda or "moment estimate"}
+           "plda": args.plda or "moment estimate", "backend": dist.get_backend() if dist.is_initialized() else None,
+           "xv_finite": bool(torch.isfinite(xv).all()), "xv_norm_max_dev": float((norms - 1.0).abs().max()),
+           "gathered_own_block_ok": gathered_own_block_ok}
     if args.all_pairs:
         # matrix-free: rank r counts the pairs (i, j), i in its enrolment-row shard, j over the whole corpus, i != j
         a, b = shard_range(N, rank, world)

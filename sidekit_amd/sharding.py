@@ -33,9 +33,11 @@ def shard_by_length(lengths, world_size):
 def gather_xvectors(local, group=None):
     """All-gather per-rank ``(N_r, D)`` blocks (N_r may differ) into the full ``(sum N_r, D)`` matrix, rank order.
 
-    One collective on the padded blocks (``all_gather_into_tensor``) plus a tiny count exchange.
+    One collective on the padded blocks (``all_gather_into_tensor``) plus a tiny count exchange.  With a process group of ONE rank the
+    collectives still run (microseconds): a single-GPU launch under ``torch.distributed.run`` then exercises the same RCCL calls the
+    N-rank job makes (``tests/test_gpu_00_multirank.py``).
     """
-    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_available() or not dist.is_initialized():
         return local
     world = dist.get_world_size(group)
     n_local = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
@@ -69,7 +71,7 @@ def score_sharded(score_rows_fn, n_enroll, group=None, dst=0):
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     start, stop = shard_range(n_enroll, rank, world)
     block = score_rows_fn(start, stop)
-    if world == 1:
+    if not dist.is_initialized():
         return block
     full = gather_xvectors(block, group)  # same ragged row gather
     return full if rank == dst else None

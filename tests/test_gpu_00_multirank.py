@@ -1,0 +1,111 @@
+"""The multi-rank code paths on real RCCL (world size 1: what a one-GPU box offers), started the way the driver starts them.
+
+This file sorts first among the GPU tests on purpose: every test here creates its `python -m torch.distributed.run ...` child
+processes from a pytest process that has not touched the GPU yet (no `gpu` fixture, `torch.cuda.device_count()` only), which is
+the launch rule of the GPU pool (no exec of, and no fork after, a GPU-initialised process).  Each child is a fresh interpreter:
+rendezvous on 127.0.0.1, `init_process_group("nccl")` = RCCL, the same `all_gather_into_tensor` / `all_reduce` calls the 8-rank
+job makes.  N > 1 on hardware is the driver's to run; the N = 2 control flow is covered on gloo in tests/test_sharding_cpu.py.
+"""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy
+import pytest
+import scipy.io.wavfile
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def _env():
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    return env
+
+
+def _torchrun(args, timeout=600):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port())] + args
+    return subprocess.run(cmd, env=_env(), cwd=ROOT, capture_output=True, text=True, timeout=timeout)
+
+
+def _plain(args, timeout=600):
+    return subprocess.run([sys.executable] + args, env=_env(), cwd=ROOT, capture_output=True, text=True, timeout=timeout)
+
+
+def _json_line(proc):
+    assert proc.returncode == 0, f"child failed ({proc.returncode}):\n{proc.stdout[-2000:]}\n{proc.stderr[-4000:]}"
+    lines = [l for l in proc.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, f"expected ONE JSON line, got {len(lines)}:\n{proc.stdout[-2000:]}"
+    return json.loads(lines[0])
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _needs_a_gpu():
+    if torch.cuda.device_count() < 1:      # counting devices does not initialise the GPU in this process
+        pytest.fail("GPU test selected but no GPU is visible (there is no CPU fallback)")
+
+
+def test_bench_one_rank_over_rccl_matches_the_plain_run():
+    """bench.py as the driver launches it for N > 1 (torch.distributed.run), with one rank: the RCCL all-gather of every step's
+    x-vectors is issued on RCCL's stream and ordered behind / ahead of the forwards as bench.py:step() says; the gathered block must
+    equal the local one (asserted inside bench.py) and the step must cost what the plain run's costs."""
+    common = ["bench.py", "--gpus", "1", "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--no-profile"]
+    d = _json_line(_torchrun(common))
+    p = _json_line(_plain(common))
+    assert "RCCL all-gather" in d["config"]["parallelism"] and "RCCL" not in p["config"]["parallelism"]
+    assert d["n_gpus"] == 1 and d["steps"] == 20 and d["dtype"] == "bf16" and d["scaling"] == "weak"
+    assert d["value"] > 0 and abs(d["value"] - 256 * 1000.0 / d["ms_per_step"]) / d["value"] < 1e-6
+    ratio = d["ms_per_step"] / p["ms_per_step"]
+    print(f"ms_per_step: torch.distributed.run x1 + RCCL gather {d['ms_per_step']:.3f}, plain {p['ms_per_step']:.3f}, ratio {ratio:.3f}")
+    assert 0.90 < ratio < 1.06, f"the all-gather stalls the step: {d['ms_per_step']:.3f} vs {p['ms_per_step']:.3f} ms"
+
+
+def test_extract_xvectors_cli_one_rank_over_rccl(tmp_path):
+    """`python -m torch.distributed.run --nproc-per-node 1 -m sidekit_amd.bin.extract_xvectors` (process group, shard = the whole
+    wav.scp, RCCL gather, rank 0 writes) against the plain invocation: the same ark bytes."""
+    from sidekit_amd.nnet.weights import seeded_state_dict
+    sd = seeded_state_dict("halfresnet34", 16, seed=5)
+    torch.save({"speaker_number": 16, "model_archi": {"model_type": "halfresnet34", "loss": {"type": "aam"}}, "model_state_dict": sd}, tmp_path / "model.pt")
+    rs = numpy.random.RandomState(0)
+    with open(tmp_path / "wav.scp", "w") as f:
+        for i in range(40):
+            x = (rs.randn(rs.randint(16000, 70000)) * 3000).astype(numpy.int16)
+            scipy.io.wavfile.write(tmp_path / f"u{i}.wav", 16000, x)
+            f.write(f"utt{i} {tmp_path}/u{i}.wav\n")
+    common = ["--model", str(tmp_path / "model.pt"), "--wav-scp", str(tmp_path / "wav.scp"), "--device", "cuda", "--batch-size", "16", "--dtype", "bf16"]
+    a = _plain(["-m", "sidekit_amd.bin.extract_xvectors", *common, "--out-scp", str(tmp_path / "a.scp")])
+    assert a.returncode == 0, a.stderr[-3000:]
+    b = _torchrun(["-m", "sidekit_amd.bin.extract_xvectors", *common, "--out-scp", str(tmp_path / "b.scp")])
+    assert b.returncode == 0, b.stderr[-3000:]
+    ark_a, ark_b = open(tmp_path / "a.ark", "rb").read(), open(tmp_path / "b.ark", "rb").read()
+    assert len(ark_a) > 40 * 1024 and ark_a == ark_b
+    keys = [l.split()[0] for l in open(tmp_path / "b.scp")]
+    assert keys == [f"utt{i}" for i in range(40)]
+
+
+def test_shard_extract_score_one_rank_over_rccl():
+    """The configs 3 + 5 driver under torch.distributed.run with one rank: ragged gather, row-sharded cosine / PLDA gathers and the
+    histogram all-reduce all go through RCCL; the numbers equal the run without a process group."""
+    args = ["-m", "sidekit_amd.bin.shard_extract_score", "--utterances", "1600", "--batch", "160", "--seconds", "1", "--trials", "500",
+            "--speakers", "40", "--plda-rank", "32", "--all-pairs"]
+    d = _json_line(_torchrun(args))
+    p = _json_line(_plain(args))
+    assert d["backend"] == "nccl" and p["backend"] is None
+    assert d["ranks"] == 1 and d["gathered_own_block_ok"] and d["xv_finite"] and d["xv_norm_max_dev"] < 1e-5
+    assert d["all_pairs"] == p["all_pairs"] == 1600 * 1599
+    for k in ("cosine_eer", "plda_eer", "all_pairs_eer"):
+        assert d[k] == p[k], (k, d[k], p[k])          # same kernels, same inputs, the collectives move data only

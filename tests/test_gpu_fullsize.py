@@ -98,6 +98,56 @@ def test_front_ends_are_stable_beside_another_streams_bf16_trunk(gpu):
         assert torch.equal(f3, ref3), (trial, int((f3 != ref3).any(dim=(1, 2)).sum()))
 
 
+def test_small_kernels_are_stable_beside_another_streams_bf16_trunk(gpu):
+    """The same regression for the two kernels that still carry packed-f32 FMAs (tests/test_isa_guard.py lists the forms): the stem
+    (explicit two-element FMAs) and the SE gate (SLP-formed `v_pk_fma_f32`, built with SLP for speed).  A second model's whole forward
+    -- stem, sixteen SE gates, pooling, tail -- runs on a side stream beside the first model's bf16 trunk, several times per trial so
+    that it overlaps every layer, in both compute dtypes, and must reproduce its solo x-vectors and logits bit for bit."""
+    m1 = Xtractor(64, model_archi="halfresnet34", loss="aam", seed=1).to(gpu).eval()
+    m2 = Xtractor(64, model_archi="halfresnet34", loss="aam", seed=2).to(gpu).eval()
+    g = torch.Generator(device="cuda").manual_seed(2)
+    a = 0.1 * torch.randn(256, 64000, device="cuda", generator=g)
+    b = 0.1 * torch.randn(48, 24000, device="cuda", generator=g)
+    m1.compute_dtype = "bf16"
+    m1.set_lanes(1)
+    m1(a, is_eval=True)
+    side = torch.cuda.Stream()
+    for dtype in ("bf16", "fp32"):
+        m2.compute_dtype = dtype
+        ref_logits, ref_emb = m2(b, is_eval=True)
+        torch.cuda.synchronize()
+        for trial in range(10):
+            m1(a, is_eval=True)                  # main stream: 5.8 ms of bf16 MFMA kernels
+            with torch.cuda.stream(side):
+                outs = [m2(b, is_eval=True) for _ in range(4 if dtype == "bf16" else 2)]
+            torch.cuda.synchronize()
+            for logits, emb in outs:
+                assert torch.equal(emb, ref_emb), (dtype, trial, int((emb != ref_emb).any(dim=1).sum()))
+                assert torch.equal(logits, ref_logits), (dtype, trial)
+
+
+def test_partial_batches_fit_the_side_lanes(gpu):
+    """with three or four lanes a batch SMALLER than the reserved one is split into fewer, larger parts (lanes = 4, reserve 256:
+    B = 255 -> three parts of 85; lanes = 3, B = 191 -> two parts of 96 / 95) and the side lanes used to be sized for ceil(256 / n) only:
+    the STFT kernel wrote past the lane's feature workspace before the call failed.  On a FRESH handle per lane count (no earlier
+    set_lanes(2) to grow lane 1) such batches must run and give the serial forward's bits."""
+    g = torch.Generator(device="cuda").manual_seed(9)
+    wav = 0.1 * torch.randn(256, 24000, device="cuda", generator=g)
+    serial = Xtractor(64, model_archi="halfresnet34", loss="aam", seed=6).to(gpu).eval()
+    serial.compute_dtype = "bf16"
+    serial.set_lanes(1)
+    refs = {B: serial(wav[:B], is_eval=True)[1].clone() for B in (256, 255, 191, 130, 127)}
+    for lanes in (4, 3):
+        m = Xtractor(64, model_archi="halfresnet34", loss="aam", seed=6).to(gpu).eval()
+        m.compute_dtype = "bf16"
+        m.set_lanes(lanes)                          # before the first forward: the handle is created with this lane count
+        assert m.get_lanes() == lanes
+        for B in (256, 255, 191, 130, 127):
+            _, emb = m(wav[:B], is_eval=True)
+            assert torch.equal(emb, refs[B]), (lanes, B, int((emb != refs[B]).any(dim=1).sum()))
+        torch.cuda.synchronize()
+
+
 def test_bf16_deviation_does_not_move_the_eer(model):
     """bf16 is judged by EER.  No trained checkpoint or dataset exists offline and a random-weight
     network maps every input to nearly the same direction (cosine 0.995 between any two), so the EER check is
@@ -160,3 +210,36 @@ def test_long_utterance_45s(model):
     finally:
         model.compute_dtype = "fp32"
     assert float(torch.nn.functional.cosine_similarity(e16, e32).min()) > 0.999
+
+
+def test_config3_100k_utterances_at_the_stated_size(model, gpu, capsys):
+    """BASELINE configs[2] at its stated size on the one GPU a box offers: 100 000 utterances x 4 s through the sharded driver
+    (`bin/shard_extract_score`, the loop that replaces sidekit/bin/extract_xvectors.py:130-150), 391 batches of 256 (the last one 160: the
+    two-lane split of a partial batch), the 1000 x 1000 trial set of config 5 scored with the reference-trained PLDA parameters of
+    tests/golden/config5.npz, and every pair of the corpus scored matrix-free.  The oracle would need half an hour for this, so the checks
+    are the size-independent properties: count, finiteness, unit norm, the gathered block sitting where the index range says, three
+    EERs in range, all-pairs count = N (N - 1)."""
+    import json
+    import os
+    from sidekit_amd.bin import shard_extract_score
+    plda = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "config5.npz")
+    model.compute_dtype = "bf16"
+    try:
+        out = shard_extract_score.main(["--utterances", "100000", "--batch", "256", "--seconds", "4", "--all-pairs", "--plda", plda], model=model)
+    finally:
+        model.compute_dtype = "fp32"
+    line = [l for l in capsys.readouterr().out.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d == json.loads(json.dumps(out))
+    N = 100000
+    assert d["ranks"] == 1 and d["utterances"] == N and d["trials"] == 1000 * 1000 and d["dtype"] == "bf16"
+    assert d["xv_finite"] and d["xv_norm_max_dev"] < 1e-5 and d["gathered_own_block_ok"]
+    assert d["all_pairs"] == N * (N - 1)
+    for k in ("cosine_eer", "plda_eer", "all_pairs_eer"):
+        assert numpy.isfinite(d[k]) and 0.0 <= d[k] < 0.5, (k, d[k])
+    assert abs(d["cosine_eer"] - d["all_pairs_eer"]) < 0.05          # the same score distribution over different trial subsets
+    assert d["x_vectors_per_s"] > 10000                                # includes the on-device synthesis of the waveforms
+    scratch = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(scratch):                                         # the r04 config-3 line under profiles/ is a copy of this file
+        with open(os.path.join(scratch, "config3_100k_one_gpu.json"), "w") as f:
+            f.write(line + "\n")
