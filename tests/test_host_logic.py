@@ -209,3 +209,43 @@ def test_shard_extract_score_load_plda(tmp_path, golden_dir):
     numpy.testing.assert_array_equal(mu2, mu)
     numpy.testing.assert_array_equal(F2, F)
     numpy.testing.assert_array_equal(Sigma2, Sigma)
+
+
+def test_compute_metrics_three_lines(tmp_path, capsys):
+    """tools/compute_metrics.py:43-45 prints EER, Cllr (min / act) and linkability.  The EER is the pinned in-tree ROCCH EER; Cllr and
+    linkability restate anonymization_metrics (un-vendored: PARITY UNPINNED) and are checked against closed forms and invariants."""
+    from sidekit_amd.bin import compute_metrics as cm
+    rs = numpy.random.RandomState(3)
+    # well-calibrated Gaussian LLRs: tar ~ N(+m, 2m), non ~ N(-m, 2m)  =>  actual Cllr ~ min Cllr, both < 1 bit
+    m = 2.0
+    tar, non = rs.normal(m, numpy.sqrt(2 * m), 4000), rs.normal(-m, numpy.sqrt(2 * m), 6000)
+    c_act, (c_min, eer) = cm.cllr(tar, non), cm.min_cllr(tar, non, compute_eer=True)
+    assert 0.0 < c_min <= c_act + 1e-12 < 1.0 and c_act - c_min < 0.02          # calibrated: PAV cannot gain much
+    assert abs(cm.cllr(numpy.zeros(5), numpy.zeros(7)) - 1.0) < 1e-12               # llr = 0 everywhere: exactly one bit
+    assert abs(cm.cllr([numpy.log(3.0)], [-numpy.log(3.0)]) - numpy.log2(4.0 / 3.0)) < 1e-12
+    assert cm.cllr([-numpy.inf], [0.0]) == numpy.inf
+    # min Cllr is invariant under any increasing map of the scores, the actual Cllr is not; the EER with it is the ROCCH EER
+    c_min2, eer2 = cm.min_cllr(numpy.tanh(tar / 10) * 7 + 3, numpy.tanh(non / 10) * 7 + 3, compute_eer=True)
+    assert abs(c_min2 - c_min) < 1e-9 and abs(eer2 - eer) < 1e-12
+    from oracle import scoring as osc
+    assert abs(eer - osc.eer(tar, non)) < 1e-12
+    # separable scores: min Cllr = 0, EER = 0, every mated score fully linkable
+    assert cm.min_cllr([2.0, 3.0, 4.0], [-1.0, 0.0, 1.0]) < 1e-5
+    d_sep = cm.linkability(rs.normal(10, 1, 2000), rs.normal(-10, 1, 2000))[0]
+    d_same = cm.linkability(rs.normal(0, 1, 20000), rs.normal(0, 1, 20000))[0]
+    d_mid = cm.linkability(tar, non)[0]
+    assert 0.95 < d_sep <= 1.0 + 1e-9 and 0.0 <= d_same < 0.12 and d_same < d_mid < d_sep
+    # the CLI: the reference's text formats in, its three lines out
+    models, segs = [f"m{i}" for i in range(20)], [f"s{j}" for j in range(30)]
+    with open(tmp_path / "scores", "w") as fs, open(tmp_path / "key", "w") as fk:
+        for i, e in enumerate(models):
+            for j, t in enumerate(segs):
+                is_tar = (i % 10) == (j % 10)
+                fs.write(f"{e} {t} {(2.0 if is_tar else -2.0) + rs.randn():.6f}\n")
+                fk.write(f"{e} {t} {'target' if is_tar else 'nontarget'}\n")
+    cm.cli(["-s", str(tmp_path / "scores"), "-k", str(tmp_path / "key")])
+    out = capsys.readouterr().out.strip().splitlines()
+    assert len(out) == 3 and out[0].startswith("EER: ") and out[1].startswith("Cllr (min/act): ") and out[2].startswith("linkability: ")
+    assert abs(float(out[0].split()[1]) / 100 - cm.eer_from_files(str(tmp_path / "scores"), str(tmp_path / "key"))) < 5e-5
+    cmin_s, cact_s = (float(x) for x in out[1].split()[2:4])
+    assert 0.0 <= cmin_s <= cact_s and 0.0 <= float(out[2].split()[1]) <= 1.0
