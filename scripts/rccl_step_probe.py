@@ -66,7 +66,7 @@ def run(variant, steps=20):
     return (time.perf_counter() - t0) / steps * 1e3, t_host / steps * 1e3
 
 
-for variant in ("none", "wait", "nowait", "sync", "every4", "lanes1_none", "lanes1_wait", "none"):
+for variant in (sys.argv[1].split(",") if len(sys.argv) > 1 else ("none", "wait", "nowait", "sync", "every4", "lanes1_none", "lanes1_wait", "none")):
     if variant.startswith("lanes1"):
         m.set_lanes(1)
         m(wavs[0], is_eval=True)

@@ -386,8 +386,47 @@ __global__ __launch_bounds__(256) void gemm_splitk_epilogue_kernel(GemmArgs g) {
   g.C[(long)m * g.ldc + n] = gemm_epilogue(g, v, m, n);
 }
 
+// the same for one row per workgroup, followed by l2_norm (loss.py:91-100) + F.normalize(eps 1e-12) (xvector.py:903) of the finished row:
+// a thread keeps its columns n = tid, tid + 256, ... in registers and squares / sums them in exactly the order l2norm_kernel (pool.hip) reads
+// them back from memory, so the x-vector is the same bits as with the two launches.  N <= 1024.
+__global__ __launch_bounds__(256) void gemm_splitk_l2norm_kernel(GemmArgs g) {
+  __shared__ float red[4];
+  const int m = blockIdx.x, tid = threadIdx.x;
+  float c[4];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int n = tid + i * 256;
+    c[i] = 0.f;
+    if (n < g.N) {
+      float v = 0.f;
+      for (int z = 0; z < g.ksplit; ++z) v += g.splitk_ws[((long)z * g.M + m) * g.N + n];
+      c[i] = gemm_epilogue(g, v, m, n);
+      g.C[(long)m * g.ldc + n] = c[i];
+      s = fmaf(c[i], c[i], s);
+    }
+  }
+  s = wave_sum(s);
+  if ((tid & 63) == 0) red[tid >> 6] = s;
+  __syncthreads();
+  const float n1 = sqrtf(red[0] + red[1] + red[2] + red[3]);
+  __syncthreads();
+  float s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    if (tid + i * 256 < g.N) { const float v = c[i] / n1; s2 = fmaf(v, v, s2); }
+  s2 = wave_sum(s2);
+  if ((tid & 63) == 0) red[tid >> 6] = s2;
+  __syncthreads();
+  const float n2 = fmaxf(sqrtf(red[0] + red[1] + red[2] + red[3]), 1e-12f);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    if (tid + i * 256 < g.N) g.l2_out[(long)m * g.N + tid + i * 256] = (c[i] / n1) / n2;
+}
+
 int launch_gemm(const GemmArgs& g_in, hipStream_t s) {
   GemmArgs g = g_in;
+  if (g.l2_done) *g.l2_done = 0;
   g.ksplit = 1; g.kslices = 1;
   { const char* e = getenv("SIDEKIT_AMD_GEMM_DBG"); g.dbg = e ? atoi(e) : 0; }
   if (g.splitk_ws && g.K >= 1024) {   // the summation order depends on K alone; M only decides where the slices run
@@ -421,7 +460,12 @@ int launch_gemm(const GemmArgs& g_in, hipStream_t s) {
   }
   SK_HIP(hipGetLastError());
   if (g.ksplit > 1) {
-    hipLaunchKernelGGL(gemm_splitk_epilogue_kernel, dim3((unsigned)(((long)g.M * g.N + 255) / 256)), dim3(256), 0, s, g);
+    if (g.l2_out && g.l2_done && g.N <= 1024) {
+      hipLaunchKernelGGL(gemm_splitk_l2norm_kernel, dim3((unsigned)g.M), dim3(256), 0, s, g);
+      *g.l2_done = 1;
+    } else {
+      hipLaunchKernelGGL(gemm_splitk_epilogue_kernel, dim3((unsigned)(((long)g.M * g.N + 255) / 256)), dim3(256), 0, s, g);
+    }
     SK_HIP(hipGetLastError());
   }
   return SK_OK;

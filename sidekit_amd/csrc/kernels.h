@@ -12,6 +12,17 @@ enum ConvShape {
   CONV_NSHAPES
 };
 
+struct SeArgs {
+  const float* se_part; const float* col_part; const float* edge;   // as written by the statistics-mode conv
+  int tiles, wm, th;
+  const void* w2t;       // conv2 weights as consumed by the MFMA, [tap][ci][co]: bf16 in the bf16 path (w2t_bf16), else f32
+  int w2t_bf16;
+  const float* scale2; const float* shift2;
+  const float* fc1; const float* fc2;   // se.fc.0 [C/16][C], se.fc.2 [C][C/16]
+  float* gate;           // [B][C]
+  Lens lens; int halvings; int wout; int C; int B;
+};
+
 struct ConvArgs {
   const void* in;      // [B][Hin][WIN][CIN]   (bf16 or f32)
   const void* wpack;   // fragment-ordered weights
@@ -58,16 +69,6 @@ int launch_stem(const float* feats, long sb, long sf, long st, const float* w, c
 // o1, so it follows from the sums conv1 left behind (total, first/last row and column, corners) and conv2's weights:
 //   mean[co] = scale2[co] / (H W) * sum_{ci,dh,dw} W2[co][ci][dh][dw] * S[ci][dh][dw] + shift2[co]
 // then FC -> ReLU -> FC -> sigmoid (res_net.py:262-281).
-struct SeArgs {
-  const float* se_part; const float* col_part; const float* edge;   // as written by the statistics-mode conv
-  int tiles, wm, th;
-  const void* w2t;       // conv2 weights as consumed by the MFMA, [tap][ci][co]: bf16 in the bf16 path (w2t_bf16), else f32
-  int w2t_bf16;
-  const float* scale2; const float* shift2;
-  const float* fc1; const float* fc2;   // se.fc.0 [C/16][C], se.fc.2 [C][C/16]
-  float* gate;           // [B][C]
-  Lens lens; int halvings; int wout; int C; int B;
-};
 int launch_se_pre(const SeArgs& a, hipStream_t s);
 
 // ---- gemm.hip ---------------------------------------------------------------------------
@@ -114,6 +115,11 @@ struct GemmArgs {
   int ksplit;           // set by launch_gemm: slices run as blockIdx.z (1: inside the workgroup)
   int kslices;          // set by launch_gemm: slices the K range is summed in (a function of K alone)
   int dbg;              // diagnostics only (SIDEKIT_AMD_GEMM_DBG, scripts/gemm_ablate.py): bit0 no operand prefetch after the first k-tile
+  // optional fused tail of the embedding GEMM: when the slices run as blockIdx.z (small M) the kernel that adds them also L2-normalises
+  // each finished row into l2_out [M][N] (the arithmetic of l2norm_kernel on the same values: same bits) and sets *l2_done = 1; otherwise
+  // *l2_done = 0 and the caller launches the normalisation itself
+  float* l2_out;
+  int* l2_done;         // host
 };
 GemmArgs gemm_args();   // zero-initialised, alpha = 1
 int launch_gemm(const GemmArgs& g, hipStream_t s);

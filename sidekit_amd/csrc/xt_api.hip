@@ -643,14 +643,14 @@ static int frontend_rows(xt_handle* h, Lane& ln, const void* d_wav, int pcm16, i
   return SK_OK;
 }
 
-static int tail(xt_handle* h, Lane& ln, int B, float* d_emb, float* d_logits, hipStream_t st) {
+static int tail(xt_handle* h, Lane& ln, int B, float* d_emb, float* d_logits, hipStream_t st, bool normalised = false) {
   const int E = h->cfg.emb_dim;
   SK_TRY(tap(h, "pre_norm", ln.ws_pre.p, (size_t)B * E * 4, st));
   if (!h->norm_embedding && h->cfg.loss == XT_LOSS_CCE) {  // xvector.py:893-898: cce + is_eval returns x as is
     SK_HIP(hipMemcpyAsync(d_emb, ln.ws_pre.p, (size_t)B * E * 4, hipMemcpyDeviceToDevice, st));
     return SK_OK;
   }
-  SK_TRY(launch_l2norm((const float*)ln.ws_pre.p, d_emb, E, B, st));
+  if (!normalised) SK_TRY(launch_l2norm((const float*)ln.ws_pre.p, d_emb, E, B, st));   // else: done by the embedding GEMM's slice-adding kernel
   if (d_logits) {
     SK_CHECK(h->head_wn != nullptr, SK_ESTATE, "logits requested but the model has no cosine head (loss='cce' returns embeddings only)");
     GemmArgs g = gemm_args();
@@ -701,6 +701,16 @@ static int half_from_feats(xt_handle* h, Lane& ln, const float* feats, long sb, 
                (size_t)B * 6 * b.C * 4 <= ln.ws_edge.bytes && (size_t)B * b.C * 4 <= ln.ws_gate.bytes, SK_EWORKSPACE,
                "SE statistics workspace too small for %d x %d frames (xt_reserve)", B, T);
     }
+    // SE gate, known before conv2 runs (linearity of the plane mean in O1): its own launch, one workgroup per utterance.  (Round 4 built
+    // the alternative the round-3 verdict asked to have measured -- conv1's last workgroup of an utterance computes the gate in its
+    // tail, an agent-scope release + ticket per workgroup -- and dropped it: at batch 256 every workgroup's release made the step
+    // 24.0 instead of 5.8 ms; selected for small batches only, the dormant tail still cost the statistics kernels their occupancy
+    // (layer 3: 161 -> 242 registers + 348 B of scratch, 6.68 ms per step); and at batch 1 the single-workgroup tail was slower than the
+    // launch it replaced (0.93 vs 0.75 ms per utterance).  DESIGN.md section 5.)
+    SeArgs se;
+    se.se_part = (const float*)ln.ws_se.p; se.col_part = (const float*)ln.ws_col.p; se.edge = (const float*)ln.ws_edge.p;
+    se.tiles = cdiv(Hl[li], b.c1.g.th); se.wm = b.c1.g.wm; se.th = b.c1.g.th; se.w2t = b.w2t; se.w2t_bf16 = h->cfg.dtype == XT_BF16; se.scale2 = b.c2.scale; se.shift2 = b.c2.shift;
+    se.fc1 = b.se_w1; se.fc2 = b.se_w2; se.gate = (float*)ln.ws_gate.p; se.lens = m.lens; se.halvings = li; se.wout = wout; se.C = b.C; se.B = B;
     { ProfScope ps(h, b.c1.shape, st); SK_TRY(launch_conv(b.c1.shape, dt, a, st)); }
     a.sc_wpack = nullptr;
     const void* shortcut = first ? SC : X;
@@ -709,11 +719,7 @@ static int half_from_feats(xt_handle* h, Lane& ln, const float* feats, long sb, 
       a.se_part = nullptr; a.col_part = nullptr; a.edge = nullptr; a.relu = 0;
       { ProfScope ps(h, b.sc.shape, st); SK_TRY(launch_conv(b.sc.shape, dt, a, st)); }
     }
-    {  // SE gate, known before conv2 runs (linearity of the plane mean in O1)
-      SeArgs se;
-      se.se_part = (const float*)ln.ws_se.p; se.col_part = (const float*)ln.ws_col.p; se.edge = (const float*)ln.ws_edge.p;
-      se.tiles = cdiv(Hl[li], b.c1.g.th); se.wm = b.c1.g.wm; se.th = b.c1.g.th; se.w2t = b.w2t; se.w2t_bf16 = h->cfg.dtype == XT_BF16; se.scale2 = b.c2.scale; se.shift2 = b.c2.shift;
-      se.fc1 = b.se_w1; se.fc2 = b.se_w2; se.gate = (float*)ln.ws_gate.p; se.lens = m.lens; se.halvings = li; se.wout = wout; se.C = b.C; se.B = B;
+    {
       ProfScope ps(h, XT_PROF_SE_RES, st);
       SK_TRY(launch_se_pre(se, st));
     }
@@ -764,8 +770,10 @@ static int half_from_feats(xt_handle* h, Lane& ln, const float* feats, long sb, 
   e.A = ln.ws_pooled.p; e.lda = 2 * D; e.a_rows = B; e.W = h->emb_w; e.ldw = 2 * D; e.C = (float*)ln.ws_pre.p;
   e.ldc = h->cfg.emb_dim; e.M = B; e.N = h->cfg.emb_dim; e.K = 2 * D; e.scale = h->emb_scale; e.shift = h->emb_shift;
   if (h->cfg.emb_dim <= 256) e.splitk_ws = (float*)ln.ws_splitk.p;
+  int l2_done = 0;
+  e.l2_out = d_emb; e.l2_done = &l2_done;     // the aam head always normalises (xvector.py:903)
   SK_TRY(launch_gemm(e, st));
-  return tail(h, ln, B, d_emb, d_logits, st);
+  return tail(h, ln, B, d_emb, d_logits, st, l2_done != 0);
 }
 
 // TDNN from CMVN'ed MFCC rows [R][80]
@@ -795,8 +803,10 @@ static int tdnn_from_rows(xt_handle* h, Lane& ln, const float* rows, const Batch
   e.A = ln.ws_pooled.p; e.lda = 3072; e.a_rows = m.B; e.W = h->emb_w; e.ldw = 3072; e.C = (float*)ln.ws_pre.p; e.ldc = h->cfg.emb_dim;
   e.M = m.B; e.N = h->cfg.emb_dim; e.K = 3072; e.bias = h->emb_bias;
   if (h->cfg.emb_dim <= 256) e.splitk_ws = (float*)ln.ws_splitk.p;
+  int l2_done = 0;
+  if (h->norm_embedding || h->cfg.loss != XT_LOSS_CCE) { e.l2_out = d_emb; e.l2_done = &l2_done; }
   SK_TRY(launch_gemm(e, st));
-  return tail(h, ln, m.B, d_emb, h->cfg.loss == XT_LOSS_AAM ? d_logits : nullptr, st);
+  return tail(h, ln, m.B, d_emb, h->cfg.loss == XT_LOSS_AAM ? d_logits : nullptr, st, l2_done != 0);
 }
 
 static int make_meta(xt_handle* h, Lane& ln, const int32_t* h_counts, int B, int64_t L_or_T, bool counts_are_samples, BatchMeta& m,
@@ -999,13 +1009,27 @@ static int reserve_lane(xt_handle* h, Lane& ln, int32_t max_batch, int64_t max_s
 static int reserve_side_lanes(xt_handle* h, int32_t max_batch, int64_t max_samples) {
   if (h->cfg.arch != XT_ARCH_HALFRESNET34) return SK_OK;
   const int n = lane_parts(h->lanes, max_batch, xt_handle::LANE_MIN);
-  for (int k = 1; k < n; ++k) {
+  for (int k = 0; k < n && n > 1; ++k) {
     Lane& lk = h->lane[k];
     if (!lk.stream) {
-      SK_HIP(hipStreamCreateWithFlags(&lk.stream, hipStreamNonBlocking));
+      // Every part of a split batch runs on a stream the handle owns (part 0 as well: the caller's stream only forks and joins), all
+      // created at ONE priority other than the caller's.  Why: the runtime multiplexes the streams of one priority onto at most
+      // GPU_MAX_HW_QUEUES (4) hardware queues, least-referenced first, and two streams on one queue run one after the other.  In a
+      // plain process the second stream created gets its own queue; in a process that has initialised RCCL (torch's pool of 32
+      // normal-priority streams exists) a normal-priority lane stream landed on the caller's queue and the two-lane forward was
+      // SLOWER than the serial one (round 4, one rank under torch.distributed.run: 6.41-6.60 vs 5.93-6.08 ms,
+      // scripts/rccl_step_probe.py).  Queues are pooled per priority, so lanes of another priority get queues of their own; and
+      // they must all have the SAME priority: one high-priority lane beside the caller's normal stream ran ahead of it instead of
+      // beside it and the overlap was gone (5.92 vs 5.73 ms).  SIDEKIT_AMD_LANE_PRIORITY = low (default) | high | normal.
+      static const char* pe = getenv("SIDEKIT_AMD_LANE_PRIORITY");
+      int least = 0, greatest = 0;
+      SK_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+      const int prio = (pe && !strcmp(pe, "normal")) ? 0 : ((pe && !strcmp(pe, "high")) ? greatest : least);
+      SK_HIP(hipStreamCreateWithPriority(&lk.stream, hipStreamNonBlocking, prio));
       SK_HIP(hipEventCreateWithFlags(&lk.fork, hipEventDisableTiming));
       SK_HIP(hipEventCreateWithFlags(&lk.join, hipEventDisableTiming));
     }
+    if (k == 0) continue;   // lane 0's workspace is the handle's full-size one
     const int part = (max_batch + k) / (k + 1);
     SK_TRY(reserve_lane(h, lk, part, max_samples));
     if (!lk.covers(part, max_samples)) lk.reserved.push_back({part, max_samples});
@@ -1064,6 +1088,7 @@ static int forward_wav(xt_handle* h, const void* d_wav, int pcm16, int64_t wav_l
   // fewer parts until every side lane exists (a handle switched after its last reserve) and its workspace covers its part: nothing
   // is enqueued before every part is known to fit
   auto parts_fit = [&](int np) {
+    if (!h->lane[0].stream) return false;
     for (int k = 1; k < np; ++k) {
       const int r0 = (int)((long)k * B / np), r1 = (int)((long)(k + 1) * B / np);
       if (!h->lane[k].stream || !h->lane[k].covers(r1 - r0, L)) return false;
@@ -1076,17 +1101,15 @@ static int forward_wav(xt_handle* h, const void* d_wav, int pcm16, int64_t wav_l
     SK_TRY(lane_frontend(h, l0, d_wav, pcm16, wav_ld, h_nsamples, B, L, m0, st));
     return lane_trunk(h, l0, m0, d_emb, d_logits, st);
   }
-  // n lanes: part k = rows [k B / n, (k + 1) B / n); part 0 on the caller's stream, the others on streams the handle owns.  A side
-  // lane starts behind everything queued on the caller's stream so far (its input may still be in flight) and the caller's stream
+  // n lanes: part k = rows [k B / n, (k + 1) B / n), every part on a stream the handle owns (reserve_side_lanes says why part 0 too).
+  // A lane starts behind everything queued on the caller's stream so far (its input may still be in flight) and the caller's stream
   // continues only once every part is done.  Round 3 found the first version of this giving a few wrong spectrum bins per batch in
   // the second lane: the STFT kernel's SLP-formed packed-f32 instructions (v_pk_add_f32 / v_pk_mul_f32 with op_sel / neg modifiers)
   // misbehave on MI355X beside another stream's dense bf16 MFMAs.  The library is built without them now (csrc/Makefile; DESIGN 6;
   // tests/test_isa_guard.py keeps them out) and tests/test_gpu_fullsize.py repeats the split forward against the serial one.
   const size_t eb = pcm16 ? 2 : 4;
-  for (int k = 1; k < n; ++k) {
-    SK_HIP(hipEventRecord(h->lane[k].fork, st));
-    SK_HIP(hipStreamWaitEvent(h->lane[k].stream, h->lane[k].fork, 0));
-  }
+  SK_HIP(hipEventRecord(h->lane[0].fork, st));
+  for (int k = 0; k < n; ++k) SK_HIP(hipStreamWaitEvent(h->lane[k].stream, h->lane[0].fork, 0));
   // An error in one part must not leave the others running unjoined: the caller's stream would no longer order behind the side
   // streams (which keep writing d_emb / d_logits) and the next call would reuse their workspaces.  So every lane that was forked
   // is joined whatever happened, and the first error is what the call returns.
@@ -1095,13 +1118,13 @@ static int forward_wav(xt_handle* h, const void* d_wav, int pcm16, int64_t wav_l
   for (int k = 0; k < n && rc == SK_OK; ++k) {
     Lane& lk = h->lane[k];
     const int r0 = (int)((long)k * B / n), r1 = (int)((long)(k + 1) * B / n);
-    hipStream_t sk_ = k ? lk.stream : st;
+    hipStream_t sk_ = lk.stream;
     BatchMeta mk;
     rc = lane_frontend(h, lk, (const unsigned char*)d_wav + (size_t)r0 * wav_ld * eb, pcm16, wav_ld, h_nsamples ? h_nsamples + r0 : nullptr, r1 - r0, L, mk, sk_);
     if (rc == SK_OK) rc = lane_trunk(h, lk, mk, d_emb + (size_t)r0 * h->cfg.emb_dim, d_logits ? d_logits + (size_t)r0 * h->cfg.n_spk : nullptr, sk_);
     if (rc != SK_OK) snprintf(first_err, sizeof(first_err), "%s", g_err);
   }
-  for (int k = 1; k < n; ++k) {
+  for (int k = 0; k < n; ++k) {
     const bool joined = hipEventRecord(h->lane[k].join, h->lane[k].stream) == hipSuccess && hipStreamWaitEvent(st, h->lane[k].join, 0) == hipSuccess;
     if (!joined) {   // last resort: drain the side stream on the host
       (void)hipStreamSynchronize(h->lane[k].stream);
