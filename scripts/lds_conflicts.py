@@ -234,3 +234,62 @@ def s2_report():
         else:           # 8 x 2 blocks: the two columns are the two halves, 3-bit key = row pair & 7
             key = lambda row, P: (row >> 1) & 7
         print(name, "planar image, %d x %d blocks: mean cycles/read %.2f, worst %d" % ((GR, GC) + s2_grid_conflicts(W, TH, CB, MW, WM, GR, GC, key)))
+
+
+# ---- stride-2 shapes, planar image, 16x16x32 MFMA (round 4) ------------------------------------------------------------------------
+def s2_m16_conflicts(W, TH, CB, WM, GR, GC, key, split_rows=True):
+    """Stride-2 3x3 conv with v_mfma_f32_16x16x32_bf16: lane l = position l & 15 of a 16-position tile (= one GR x GC block of the
+    output tile: block row wm, block column t) and 16-B chunk 4 s + (l >> 4).  A read group carries chunk q for tile positions
+    {0-3, 12-15} and chunk q + 1 for {4-11}; with `split_rows` those two halves are the upper and the lower half of the block's rows
+    (positions 0-3, 12-15 -> rows [0, GR/2), positions 4-11 -> rows [GR/2, GR)), so that the row part of the key separates them."""
+    WOUT, SPP, KS32 = W // 2, CB // 16, CB // 64
+    RS = (W + 1) * CB
+    NBC = WOUT // GC
+    assert WOUT % GC == 0 and TH == WM * GR
+    def planar(col):
+        if col < 0 or col >= W:
+            return W
+        return (col & 1) * (W // 2) + (col >> 1)
+    def blockpos(p):
+        if not split_rows:
+            return p // GC, p % GC
+        j = p if p < 4 else (p - 8 if p >= 12 else p - 4)           # index inside its half (0..7)
+        half = 1 if 4 <= p < 12 else 0
+        if split_rows == "parity":                                  # 8 x 2 blocks: even rows / odd rows
+            return 2 * (j // GC) + half, j % GC
+        return half * (GR // 2) + j // GC, j % GC
+    total = reads = worst = 0
+    for wm in range(WM):
+        for t in range(NBC):
+            for dh in range(3):
+                for dw in range(3):
+                    for s in range(KS32):
+                        addrs = []
+                        for lane in range(64):
+                            p, q = lane & 15, lane >> 4
+                            pr, pc = blockpos(p)
+                            ho, wo = wm * GR + pr, t * GC + pc
+                            row, P = 2 * ho + dh, planar(2 * wo + dw - 1)
+                            c = 4 * s + q
+                            addrs.append(row * RS + P * CB + (((c ^ key(row, P)) & (SPP - 1)) << 4))
+                        cyc = read_cycles(addrs)
+                        total += cyc; reads += 1; worst = max(worst, cyc)
+    return total / reads, worst
+
+
+def s2_m16_report():
+    shapes = {"L2A": (80, 4, 64, 2, 2, 8), "L3A": (40, 4, 128, 1, 4, 4), "L4A": (20, 8, 128, 1, 8, 2)}
+    for name, (W, TH, CB, WM, GR, GC) in shapes.items():
+        SPP = CB // 16
+        if SPP == 4:
+            key = lambda row, P: ((((row >> 1) & 1) << 1) | ((P >> 2) & 1))
+        elif GC == 4:
+            key = lambda row, P: ((((row >> 1) & 3) << 1) | ((P >> 1) & 1))
+        else:   # 8 x 2 blocks: 3-bit row key rotated left by one (key bit 0 = bit 2 of the row pair), halves = even / odd rows: two rows whose
+                # keys differ in bit 0 alone are then 4 apart, i.e. in the same half, and the chunk difference of 1 between the halves cannot
+                # map two of their positions onto one slot -- under the (dh = 2) shift of the row pair as well
+            rot = lambda h: ((h << 1) & 7) | (h >> 2)
+            key = lambda row, P: rot((row >> 1) & 7)
+        for sr in ((False, True, "parity") if GR == 8 else (False, True)):
+            print(name, "planar image, 16x16x32 operand reads, %d x %d blocks, halves = row halves: %s -> mean cycles/read %.2f, worst %d"
+                  % ((GR, GC, sr) + s2_m16_conflicts(W, TH, CB, WM, GR, GC, key, sr)))

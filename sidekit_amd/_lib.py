@@ -9,6 +9,8 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libsidekit_amd.so")
+if os.environ.get("SIDEKIT_AMD_LIB"):   # tuning aid: another build of the SAME library (A/B runs of kernel variants); never a different backend
+    LIB_PATH = os.path.abspath(os.environ["SIDEKIT_AMD_LIB"])
 
 SK_OK, SK_EARG, SK_ESHAPE, SK_EHIP, SK_EWORKSPACE, SK_ESTATE = 0, -1, -2, -3, -4, -5
 XT_ARCH_HALFRESNET34, XT_ARCH_TDNN = 0, 1

@@ -693,7 +693,7 @@ static int half_from_feats(xt_handle* h, Lane& ln, const float* feats, long sb, 
     // (no shortcut tensor at all); the older forms -- riding on conv1's centre tap, or a separate 1x1 launch -- remain
     // for A/B runs (SIDEKIT_AMD_SHORTCUT_TENSOR=1)
     const bool inplace_sc = first && !h->shortcut_tensor;
-    const bool fuse_sc = first && !inplace_sc && b.c1.g.stride == 2 && b.c1.g.nw == 1 && b.sc.g.ck == b.c1.g.ck;
+    const bool fuse_sc = first && !inplace_sc && b.c1.g.stride == 2 && b.c1.g.nw == 1 && b.sc.g.ck == b.c1.g.ck && !b.c1.g.m16;   // (the 16x16x32 k-loop has no fused-shortcut form)
     if (fuse_sc) { a.sc_wpack = b.sc.wpack; a.sc_scale = b.sc.scale; a.sc_shift = b.sc.shift; a.sc_out = SC; }
     {
       const size_t tiles1 = (size_t)cdiv(Hl[li], b.c1.g.th);
