@@ -24,17 +24,46 @@ constexpr int se_chunk(int nit) {
 template <typename WT, int C_>
 __global__ __launch_bounds__(1024) void se_pre_kernel(SeArgs a) {
   constexpr int VEC = 16 / sizeof(WT);
-  __shared__ float red[8 * 1024];   // phase 1: 3 x 1024; phase 2: [KG][C] partial sums (KG * C = 1024 * VEC / ... <= 8192)
-  __shared__ float S[9 * 256];
+  __shared__ float red[8 * 1024];   // phase 1: 3 x 1024; phase 2: [KG][C] partial sums (KG * C = 1024 * VEC / ... <= 8192); phase 3: the two FC weight matrices
+  __shared__ float S[9 * 256];      // phase 3: FC1's slice partials
   __shared__ float y[256];
   __shared__ float hid[16];
-  constexpr int C = C_, G = 1024 / C;
+  constexpr int C = C_, G = 1024 / C, R = C / 16;
   const int b = blockIdx.x, c = threadIdx.x % C, g = threadIdx.x / C;
+  // (0) Everything that does not depend on this launch's sums is requested FIRST (round 4): the two FC weight matrices (C * C / 16 floats
+  // each, parked in registers until phase 3 and read from LDS there), conv2's BatchNorm constants and the first CH conv2-weight rows of
+  // phase 2.  The kernel is a chain of dependent L2 round trips (a batch-1 forward spends 146 us in sixteen of these launches for almost no
+  // arithmetic); these four used to sit behind the phases that consume them.  Values and summation order are unchanged: same bits.
+  constexpr int NF = C * R, NPF = (NF + 1023) / 1024;
+  float pf1[NPF], pf2[NPF];
+#pragma unroll
+  for (int i = 0; i < NPF; ++i) {
+    const int idx = threadIdx.x + i * 1024;
+    pf1[i] = idx < NF ? a.fc1[idx] : 0.f;
+    pf2[i] = idx < NF ? a.fc2[idx] : 0.f;
+  }
+  const float psc = a.scale2[c], psh = a.shift2[c];
+  constexpr int CG = C / VEC, KG = 1024 / CG;
+  const int cg = threadIdx.x % CG, kg = threadIdx.x / CG;
+  const unsigned char* wp = reinterpret_cast<const unsigned char*>(a.w2t) + (size_t)cg * 16;
+  // k = tap * C + ci, this thread's rows k = kg + i * KG.  The loop is a chain of L2 latencies (72 dependent rounds of one 16-B load at
+  // C = 256 were 55 us, eight in flight 20 us): the trip count is a compile-time constant, so up to 24 loads are issued back to back
+  // (three rounds at C = 256, one at C <= 128) and the FMAs follow in k order -- the sums are those of the rolled loop.
+  constexpr int NIT = (9 * C + KG - 1) / KG, CH = se_chunk(NIT);   // the largest divisor of the trip count up to 24
+  constexpr bool EARLY = C <= 128;   // C = 256: 24 rows in flight + the parked FC weights do not fit the 128 registers of a 1024-thread workgroup
+  uint4 w[CH];
+  if constexpr (EARLY) {
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      const int k = kg + i * KG;
+      w[i] = k < 9 * C ? *reinterpret_cast<const uint4*>(wp + (size_t)k * C * sizeof(WT)) : make_uint4(0, 0, 0, 0);
+    }
+  }
   const int hb = halve(a.lens.get(b), a.halvings);
   const int nt = (hb + a.th - 1) / a.th;
   float T = 0.f, C0 = 0.f, CL = 0.f;
   for (int t = g; t < nt; t += G) {
-    for (int w = 0; w < a.wm; ++w) T += a.se_part[(((size_t)b * a.tiles + t) * a.wm + w) * C + c];
+    for (int wv = 0; wv < a.wm; ++wv) T += a.se_part[(((size_t)b * a.tiles + t) * a.wm + wv) * C + c];
     C0 += a.col_part[((size_t)b * a.tiles + t) * 2 * C + c];
     CL += a.col_part[((size_t)b * a.tiles + t) * 2 * C + C + c];
   }
@@ -58,23 +87,17 @@ __global__ __launch_bounds__(1024) void se_pre_kernel(SeArgs a) {
   }
   __syncthreads();
   {
-    constexpr int CG = C / VEC, KG = 1024 / CG;
-    const int cg = threadIdx.x % CG, kg = threadIdx.x / CG;
     float m[VEC];
 #pragma unroll
     for (int v = 0; v < VEC; ++v) m[v] = 0.f;
-    const unsigned char* wp = reinterpret_cast<const unsigned char*>(a.w2t) + (size_t)cg * 16;
-    // k = tap * C + ci, this thread's rows k = kg + i * KG.  The loop is a chain of L2 latencies (72 dependent rounds of one 16-B load at
-    // C = 256 were 55 us, eight in flight 20 us): the trip count is a compile-time constant, so up to 24 loads are issued back to back
-    // (three rounds at C = 256, one at C <= 128) and the FMAs follow in k order -- the sums are those of the rolled loop.
-    constexpr int NIT = (9 * C + KG - 1) / KG, CH = se_chunk(NIT);   // the largest divisor of the trip count up to 24
 #pragma unroll 1
     for (int i0 = 0; i0 < NIT; i0 += CH) {
-      uint4 w[CH];
+      if (i0 || !EARLY) {   // the first chunk was requested at the top of the kernel (C <= 128)
 #pragma unroll
-      for (int i = 0; i < CH; ++i) {
-        const int k = kg + (i0 + i) * KG;
-        w[i] = k < 9 * C ? *reinterpret_cast<const uint4*>(wp + (size_t)k * C * sizeof(WT)) : make_uint4(0, 0, 0, 0);
+        for (int i = 0; i < CH; ++i) {
+          const int k = kg + (i0 + i) * KG;
+          w[i] = k < 9 * C ? *reinterpret_cast<const uint4*>(wp + (size_t)k * C * sizeof(WT)) : make_uint4(0, 0, 0, 0);
+        }
       }
 #pragma unroll
       for (int i = 0; i < CH; ++i) {
@@ -109,30 +132,36 @@ __global__ __launch_bounds__(1024) void se_pre_kernel(SeArgs a) {
     if (g == 0) {
       float t = 0.f;
       for (int q = 0; q < G; ++q) t += red[q * C + c];
-      y[c] = t / (float)(hb * a.wout) * a.scale2[c] + a.shift2[c];
+      y[c] = t / (float)(hb * a.wout) * psc + psh;
     }
   }
   __syncthreads();
-  const int R = C / 16;
+  // phase 3: the FC weights parked in registers go to LDS (red is free now): fc1 [R][C] at red[0 ..), fc2 [C][R] at red[4096 ..)
+#pragma unroll
+  for (int i = 0; i < NPF; ++i) {
+    const int idx = threadIdx.x + i * 1024;
+    if (idx < NF) { red[idx] = pf1[i]; red[4096 + idx] = pf2[i]; }
+  }
+  __syncthreads();
   {  // FC1 (R x C): all threads, thread = (hidden unit r, slice of 16 input channels), slices added in order
     const int NS = C / 16, r1 = threadIdx.x % R, sl = threadIdx.x / R;   // R * NS = C * C / 256 <= 256 threads
     if (sl < NS) {
       float s = 0.f;
 #pragma unroll
-      for (int k = 0; k < 16; ++k) s = fmaf(a.fc1[r1 * C + sl * 16 + k], y[sl * 16 + k], s);
-      red[sl * R + r1] = s;
+      for (int k = 0; k < 16; ++k) s = fmaf(red[r1 * C + sl * 16 + k], y[sl * 16 + k], s);
+      S[sl * R + r1] = s;
     }
     __syncthreads();
     if (threadIdx.x < R) {
       float s = 0.f;
-      for (int q = 0; q < NS; ++q) s += red[q * R + threadIdx.x];
+      for (int q = 0; q < NS; ++q) s += S[q * R + threadIdx.x];
       hid[threadIdx.x] = relu_nan(s);
     }
   }
   __syncthreads();
   if (g == 0) {
     float z = 0.f;
-    for (int k = 0; k < R; ++k) z = fmaf(a.fc2[c * R + k], hid[k], z);
+    for (int k = 0; k < R; ++k) z = fmaf(red[4096 + c * R + k], hid[k], z);
     a.gate[(size_t)b * C + c] = 1.f / (1.f + expf(-z));
   }
 }
