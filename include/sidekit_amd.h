@@ -158,6 +158,10 @@ int sc_cosine(const float* d_E, int32_t Ne, const float* d_T, int32_t Nt, int32_
 int sc_plda_fast(const double* d_E, int32_t Ne, const double* d_T, int32_t Nt, int32_t D, const double* d_Phi,
                  const double* d_Psi, double cst, double scaling, double* d_out, void* stream);
 
+/* torch.nn.functional.normalize(x, dim=1) (eps 1e-12) on the device: what the reference applies to cohort and test x-vectors before
+ * cosine scoring (sidekit/score_normalization.py:128, sidekit/nnet/xvector.py:243,258-259).  d_out may alias d_X. */
+int sc_normalize_rows(const float* d_X, int32_t N, int32_t D, float* d_out, void* stream);
+
 /* sc_plda_fast keeps its intermediate buffer (E.Psi and the quadratic-form partials) cached per (device, stream) so that a call
  * allocates nothing; this frees every cached buffer (after a device synchronise).  The Python shim calls it at interpreter exit;
  * a long-lived host that creates and destroys many streams may call it whenever no sc_plda_fast call is in flight.  The reference

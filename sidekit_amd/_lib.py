@@ -54,6 +54,7 @@ SIGNATURES = {
     "sc_cosine": (ctypes.c_int, [_P, _I32, _P, _I32, _I32, _P, _P]),
     "sc_plda_fast": (ctypes.c_int, [_P, _I32, _P, _I32, _I32, _P, _P, _F64, _F64, _P, _P]),
     "sc_release_workspace": (ctypes.c_int, []),
+    "sc_normalize_rows": (ctypes.c_int, [_P, _I32, _I32, _P, _P]),
     "sc_cosine_hist": (ctypes.c_int, [_P, _I32, _P, _I32, _I32, _P, _P, _I32, ctypes.c_float, ctypes.c_float, _I32, _P, _P, _P]),
     "sc_cosine_trials": (ctypes.c_int, [_P, _P, _I32, _P, _P, _I64, _P, _P]),
     "sc_topk_stats": (ctypes.c_int, [_P, _I32, _I32, _I32, _P, _P, _P]),

@@ -170,5 +170,7 @@ int launch_att_fused(const void* x_bf16, const float* h, const void* w2_bf16, co
 int launch_cmvn(float* x, long ld, int D, RowSpan rs, float eps, int B, hipStream_t s);
 // x / ||x||_2 (loss.py:91-100) followed by F.normalize(eps=1e-12) (xvector.py:903)
 int launch_l2norm(const float* x, float* out, int D, int B, hipStream_t s);
+// x / max(||x||_2, eps) per row (F.normalize)
+int launch_normalize_rows(const float* x, float* out, int D, int B, float eps, hipStream_t s);
 
 }  // namespace sk

@@ -403,6 +403,26 @@ __global__ __launch_bounds__(256) void l2norm_kernel(const float* __restrict__ x
   for (int d = tid; d < D; d += 256) out[(long)b * D + d] = (x[(long)b * D + d] / n1) / n2;
 }
 
+// out = x / max(||x||_2, eps): torch.nn.functional.normalize(x, dim=1) as the reference applies it to cohort / test x-vectors before
+// cosine scoring (sidekit/score_normalization.py:128, sidekit/nnet/xvector.py:243,258-259)
+__global__ __launch_bounds__(256) void normalize_rows_kernel(const float* __restrict__ x, float* __restrict__ out, int D, float eps) {
+  __shared__ float red[4];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  float s = 0.f;
+  for (int d = tid; d < D; d += 256) { const float v = x[(long)b * D + d]; s = fmaf(v, v, s); }
+  s = wave_sum(s);
+  if ((tid & 63) == 0) red[tid >> 6] = s;
+  __syncthreads();
+  const float n = fmaxf(sqrtf(red[0] + red[1] + red[2] + red[3]), eps);
+  for (int d = tid; d < D; d += 256) out[(long)b * D + d] = x[(long)b * D + d] / n;
+}
+
+int launch_normalize_rows(const float* x, float* out, int D, int B, float eps, hipStream_t s) {
+  hipLaunchKernelGGL(normalize_rows_kernel, dim3(B), dim3(256), 0, s, x, out, D, eps);
+  SK_HIP(hipGetLastError());
+  return SK_OK;
+}
+
 int launch_l2norm(const float* x, float* out, int D, int B, hipStream_t s) {
   hipLaunchKernelGGL(l2norm_kernel, dim3(B), dim3(256), 0, s, x, out, D);
   SK_HIP(hipGetLastError());

@@ -479,6 +479,11 @@ int sc_plda_fast(const double* d_E, int32_t Ne, const double* d_T, int32_t Nt, i
   return SK_OK;
 }
 
+int sc_normalize_rows(const float* d_X, int32_t N, int32_t D, float* d_out, void* stream) {
+  SK_CHECK(d_X && d_out && N > 0 && D > 0, SK_EARG, "sc_normalize_rows: bad arguments");
+  return launch_normalize_rows(d_X, d_out, D, N, 1e-12f, (hipStream_t)stream);
+}
+
 int sc_release_workspace(void) {
   std::lock_guard<std::mutex> lock(g_plda_mu);
   int cur = 0;

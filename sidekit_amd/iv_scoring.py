@@ -70,6 +70,16 @@ def cosine_matrix_device(enroll_vectors, test_vectors, device=None):
     return out
 
 
+def normalize_rows_device(vectors, device=None):
+    """``torch.nn.functional.normalize(x, dim=1)`` on the GPU (``sc_normalize_rows``): (N, D) -> float32 **device tensor** of unit rows."""
+    device = _device(device if device is not None else (vectors.device if torch.is_tensor(vectors) and vectors.is_cuda else None))
+    x = _to_device(vectors, torch.float32, device)
+    out = torch.empty_like(x)
+    with torch.cuda.device(device):
+        _lib.check(_lib.lib().sc_normalize_rows(x.data_ptr(), x.shape[0], x.shape[1], out.data_ptr(), _stream(device)), AssertionError)
+    return out
+
+
 def cosine_matrix(enroll_vectors, test_vectors, device=None):
     """(Ne, D) x (Nt, D) already-normalised float vectors -> (Ne, Nt) float32 numpy matrix (computed on the GPU)."""
     return cosine_matrix_device(enroll_vectors, test_vectors, device).cpu().numpy()

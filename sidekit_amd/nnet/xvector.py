@@ -538,14 +538,15 @@ def test_metrics(model, device, model_opts, data_opts, train_opts, as_norm=True)
         return cls.read_txt(x) if str(x).endswith(".txt") else cls(x)
 
     ndx, key = load(Ndx, data_opts["test"]["ndx"]), load(Key, data_opts["test"]["key"])
-    tsr = torch.nn.functional.normalize(torch.as_tensor(xv_stat.stat1, dtype=torch.float32), dim=1)
+    from ..iv_scoring import normalize_rows_device
+    tsr = normalize_rows_device(torch.as_tensor(xv_stat.stat1, dtype=torch.float32))       # F.normalize, on the device (stays there)
     scores = cosine_matrix(tsr, tsr)[ndx.trialmask]
     tar, non = key.tar[ndx.trialmask], key.non[ndx.trialmask]
     pmiss, pfa = rocch(scores[tar], scores[non])
     if not as_norm:
         return rocch2eer(pmiss, pfa)
     cohort = torch.as_tensor(model.state_dict()["after_speaker_embedding.weight"], dtype=torch.float32)
-    s_scores = asnorm(tsr, torch.nn.functional.normalize(cohort, dim=1), ndx)[ndx.trialmask]
+    s_scores = asnorm(tsr, normalize_rows_device(cohort), ndx)[ndx.trialmask]               # xvector.py:258; asnorm normalises once more, as in the reference (score_normalization.py:128)
     norm_pmiss, norm_pfa = rocch(s_scores[tar], s_scores[non])
     return rocch2eer(pmiss, pfa), rocch2eer(norm_pmiss, norm_pfa)
 

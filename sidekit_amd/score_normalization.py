@@ -25,7 +25,8 @@ def asnorm(enrol_xv, cohort_xv, ndx=None, topk=200, device=None):
         raise RuntimeError("sidekit_amd computes on the GPU only (no CPU fallback) and no GPU is visible")
     device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
     e = torch.as_tensor(enrol_xv, dtype=torch.float32).to(device).contiguous()
-    c = torch.nn.functional.normalize(torch.as_tensor(cohort_xv, dtype=torch.float32), dim=1).to(device).contiguous()
+    from .iv_scoring import normalize_rows_device
+    c = normalize_rows_device(torch.as_tensor(cohort_xv, dtype=torch.float32), device)     # F.normalize of the cohort, on the device
     n, d = e.shape
     if d % 4 or c.shape[1] != d:
         raise ValueError("x-vector dimension must match and be a multiple of 4")
