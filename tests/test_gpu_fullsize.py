@@ -243,3 +243,42 @@ def test_config3_100k_utterances_at_the_stated_size(model, gpu, capsys):
     if os.path.isdir(scratch):                                         # the r04 config-3 line under profiles/ is a copy of this file
         with open(os.path.join(scratch, "config3_100k_one_gpu.json"), "w") as f:
             f.write(line + "\n")
+
+
+def test_error_in_a_side_lane_joins_every_lane(gpu):
+    """an error after the fork (here: an utterance of the SECOND part too short for the reflect padding, caught by that part's
+    length check once part 0 is already queued) must not leave a forked lane running unjoined -- the call raises, the caller's stream still
+    orders behind every lane, and the next forwards on the same handle give the serial forward's bits."""
+    m = Xtractor(64, model_archi="halfresnet34", loss="aam", seed=8).to(gpu).eval()
+    m.compute_dtype = "bf16"
+    g = torch.Generator(device="cuda").manual_seed(4)
+    wav = 0.1 * torch.randn(256, 32000, device="cuda", generator=g)
+    m.set_lanes(1)
+    ref = m(wav, is_eval=True)[1].clone()
+    m.set_lanes(2)
+    assert torch.equal(m(wav, is_eval=True)[1], ref)
+    lens = [32000] * 256
+    lens[200] = 300                                   # n_fft / 2 = 512 samples are the minimum: part 1 (rows 128..255) fails, part 0 is queued
+    for _ in range(3):
+        with pytest.raises(ValueError):
+            m(wav, is_eval=True, lengths=lens)
+        assert torch.equal(m(wav, is_eval=True)[1], ref)
+    torch.cuda.synchronize()
+    lens[200], lens[10] = 32000, 300                  # and in part 0: nothing has been forked yet
+    with pytest.raises(ValueError):
+        m(wav, is_eval=True, lengths=lens)
+    assert torch.equal(m(wav, is_eval=True)[1], ref)
+
+
+def test_normalize_rows_matches_torch(gpu):
+    """sc_normalize_rows = torch.nn.functional.normalize(x, dim=1) (sidekit/score_normalization.py:128, nnet/xvector.py:243): unit rows, zero rows
+    stay zero (eps), float32 rounding apart."""
+    from sidekit_amd.iv_scoring import normalize_rows_device
+    x = torch.randn(1000, 256, generator=torch.Generator().manual_seed(0))
+    x[17] = 0.0
+    got = normalize_rows_device(x).cpu()
+    want = torch.nn.functional.normalize(x, dim=1)
+    assert got.shape == want.shape and torch.equal(got[17], torch.zeros(256))
+    assert float((got - want).abs().max()) < 2e-7
+    x2 = torch.randn(33, 100)                        # a dimension that is not a multiple of 4 or 64
+    assert float((normalize_rows_device(x2).cpu() - torch.nn.functional.normalize(x2, dim=1)).abs().max()) < 2e-7
