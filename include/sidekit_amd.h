@@ -100,7 +100,8 @@ int xt_set_norm_embedding(xt_handle* h, int32_t on);
 /* Split forward.  With lanes = n (default 2, at most 4; SIDEKIT_AMD_LANES in the environment or xt_set_lanes) a HalfResNet34 batch
  * of >= 128 utterances is forwarded as up to n parts of at least 64 utterances on n HIP streams (the caller's and n - 1 the handle
  * owns): one part's latency-bound kernels run under another part's convolutions.  Results do not change (every kernel is batch-size
- * invariant).  lanes = 1 serialises the forward again, for profiles in which one kernel's duration has to mean something.
+ * invariant).  lanes = 1 serialises the forward again, for profiles in which one kernel's duration has to mean something.  Measured on MI355X: two and three
+ * lanes are 1-4 % faster than one, FOUR are slower (a constant +2.3 ms per forward: the fourth lane's stream shares a hardware queue).
  * The reference has no counterpart: its forward is one
  * stream of cuDNN calls (sidekit/nnet/xvector.py:876-907). */
 int xt_set_lanes(xt_handle* h, int32_t lanes);
