@@ -20,13 +20,15 @@ prints ONE JSON line.  Two extra objects ride on that line:
   cpu_baseline the oracle's CPU restatement of the same forward, timed on this box's host cores
                on a bounded sample at batch 16 and batch 1 (rank 0, N = 1 only).
 
-The timed region runs the PRODUCT configuration: the two-lane forward (a batch of >= 128 utterances goes as two halves on two
-HIP streams, `xt_set_lanes`), in which kernels of the two halves overlap and one kernel's duration says nothing about that
-kernel.  The roofline object therefore comes from a second region of the same K steps with the lanes serialised
-(`roofline.measured_in` says so; `--lanes 1` runs everything serial, then it IS the timed region), and
-`profiles/` holds the rocprofv3 trace of the serial run.  `roofline.traffic` is not observed by this run: it is replayed
-from `profiles/traffic.json` (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command), `traffic_source` names the file
-and its capture.
+The timed region runs the PRODUCT configuration of a corpus run: batches are issued through `Xtractor.submit` / `collect`
+(`xt_forward_begin` / `xt_forward_end`), two WHOLE batches in flight on two streams of the handle, half a step apart -- what
+`sidekit_amd.pipeline.StreamingExtractor` does with the batches of a wav.scp.  A step submits one batch and collects the one submitted a
+step earlier; every batch submitted inside the timed region is collected inside it.  (`--pipeline 1` times one forward at a time: the
+two-lane split of a batch, `xt_set_lanes`.)  Either way kernels of two batches / half batches overlap and one kernel's duration says
+nothing about that kernel.  The roofline object therefore comes from a second region of the same K steps, one forward at a time on
+one stream (`roofline.measured_in` says so), and `profiles/` holds the rocprofv3 trace of the serial run.  `roofline.traffic` is not
+observed by this run: it is replayed from `profiles/traffic.json` (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command),
+`traffic_source` names the file and its capture.
 
 `--gpus N` (N > 1) started WITHOUT torch.distributed.run in the environment launches its N ranks
 itself: a fresh `python -m torch.distributed.run ... bench.py` child is created before this process
@@ -322,7 +324,9 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--arch", default="halfresnet34", choices=["halfresnet34", "xvector"])
     ap.add_argument("--ragged", action="store_true", help="variable-length 2-10 s utterances (BASELINE configs[3] with --arch xvector --dtype fp32 --batch 512)")
-    ap.add_argument("--lanes", type=int, default=0, choices=[0, 1, 2], help="0: the library default (two-lane forward), 1: serial, 2: two lanes")
+    ap.add_argument("--lanes", type=int, default=0, choices=[0, 1, 2], help="0: the library default (two-lane forward), 1: serial, 2: two lanes (only without --pipeline)")
+    ap.add_argument("--pipeline", type=int, default=2, choices=[1, 2], help="2 (default): the steps are issued through Xtractor.submit / collect, two whole batches in flight on two "
+                    "streams of the handle (what the streaming extractor does); 1: one forward at a time (the two-lane split of a batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--dry-run", action="store_true", help="CPU/gloo stand-in of the loop (plumbing test, not a measurement)")
@@ -368,25 +372,49 @@ def main():
     # region ends after every gather has completed
     gathered = [torch.empty(world * B, model.embedding_size, device=dev) for _ in range(2)] if use_dist else None
     counter = [0]
+    gathers = [0]
     in_flight = []
+    pending = []           # tickets of submitted, not yet collected batches (pipeline 2)
+    pipelined = args.pipeline > 1
+
+    def gather(emb):
+        k = gathers[0]
+        gathers[0] += 1
+        while len(in_flight) >= 2:
+            in_flight.pop(0)[0].wait()
+        work = dist.all_gather_into_tensor(gathered[k % 2], emb, async_op=True)
+        # the next kernels on the compute stream are ordered behind the collective (a stream-side wait, the host does not block):
+        # 256 KB per rank is microseconds (0.05-0.09 ms per step)
+        work.wait()
+        in_flight.append((work, emb))
 
     def step():
+        """One pass of the hot path over one batch.  Pipelined (default): the batch is SUBMITTED -- its whole forward queued on one of the
+        handle's two slot streams -- and the batch submitted one step earlier is COLLECTED (and gathered), so two batches are in flight, half
+        a step apart; every batch submitted inside a timed region is collected inside it (drain)."""
         wav = wavs[counter[0] % len(wavs)]
-        k = counter[0]
         counter[0] += 1
-        _, emb = model(wav, is_eval=True, lengths=lens)
-        if use_dist:
-            while len(in_flight) >= 2:
-                in_flight.pop(0)[0].wait()
-            work = dist.all_gather_into_tensor(gathered[k % 2], emb, async_op=True)
-            # the next step's kernels are ordered behind the collective on the compute stream (a stream-side wait, the host does
-            # not block): 256 KB per rank is microseconds, and the front-end kernel is not run beside a kernel of another stream
-            # (the two-lane hazard)
-            work.wait()
-            in_flight.append((work, emb))
+        if pipelined:
+            pending.append(model.submit(wav, lengths=lens))
+            emb = None
+            if len(pending) == model.pipeline_depth:
+                emb = model.collect(pending.pop(0))[1]
+        else:
+            _, emb = model(wav, is_eval=True, lengths=lens)
+        if use_dist and emb is not None:
+            gather(emb)
+        if emb is not None:
+            last[0] = emb
         return emb
 
+    last = [None]
+
     def drain():
+        while pending:
+            emb = model.collect(pending.pop(0))[1]
+            last[0] = emb
+            if use_dist:
+                gather(emb)
         while in_flight:
             in_flight.pop(0)[0].wait()
 
@@ -394,6 +422,7 @@ def main():
         model.set_lanes(args.lanes)
     model(wavs[0], is_eval=True, lengths=lens)          # creates the handle and reserves the workspace (both lanes)
     lanes = model.get_lanes() if (args.arch == "halfresnet34" and B >= 128) else 1
+    overlapped = pipelined or lanes > 1                 # kernels of two batches / two half batches run side by side in the timed region
 
     host_enqueue = [0.0]
 
@@ -405,14 +434,14 @@ def main():
             torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
         for _ in range(n_steps):
-            e = step()
+            step()
         host_enqueue[0] = time.perf_counter() - t0      # the host's share: every launch of the K steps is queued, nothing awaited yet
         drain()
         torch.cuda.synchronize(dev)
         if use_dist:
             dist.barrier()
             torch.cuda.synchronize(dev)
-        return time.perf_counter() - t0, e
+        return time.perf_counter() - t0, last[0]
 
     # Measurement plan.  An event pair per kernel launch costs ~2 us of stream time (150 pairs per step = 4-6 % of the step), and
     # with two lanes a kernel's duration includes whatever the other lane ran beside it.  So: (1) W warmup + exactly K timed steps
@@ -428,7 +457,7 @@ def main():
         convs = {k: v for k, v in prof_w.items() if k in CONV_SHAPES}
         return pc, (sorted(convs, key=lambda k: -convs[k][0])[:2] if convs else None)
 
-    n_prof_warm = min(3, args.warmup) if (profile and lanes == 1) else 0
+    n_prof_warm = min(3, args.warmup) if (profile and not overlapped) else 0
     for i in range(args.warmup):
         if n_prof_warm and i == args.warmup - n_prof_warm:
             model.set_profile(True)
@@ -437,17 +466,18 @@ def main():
     if n_prof_warm:
         per_class, focus = pick_focus(model.get_profile(reset=True), n_prof_warm)
         n_prof = n_prof_warm
-    if profile and lanes == 1:
+    if profile and not overlapped:
         model.set_profile(True, slots=focus) if focus else model.set_profile(True)
         model.get_profile(reset=True)
+    drain()                                             # warm-up batches still in flight are collected outside the timed region
     dt, emb = timed_region(args.steps)
     assert bool(torch.isfinite(emb).all()), "non-finite x-vectors"
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        assert torch.equal(gathered[(counter[0] - 1) % 2][rank * B:(rank + 1) * B], emb), "all-gather returned a different block for this rank"
+        assert torch.equal(gathered[(gathers[0] - 1) % 2][rank * B:(rank + 1) * B], emb), "all-gather returned a different block for this rank"
     dt = t.item()
-    if profile and lanes == 1:
+    if profile and not overlapped:
         prof = model.get_profile(reset=True)
         measured_in = "the timed region (serial lanes)"
     elif profile and rank == 0:
@@ -475,8 +505,8 @@ def main():
         prof = model.get_profile(reset=True)
         model.set_profile(False)
         model.set_lanes(lanes)
-        measured_in = (f"a second region of {args.steps} steps with the lanes serialised (xt_set_lanes 1, {serial_ms:.3f} ms per step), run after the "
-                       f"timed region: in the {lanes}-lane timed region kernels of the two half batches overlap")
+        measured_in = (f"a second region of {args.steps} steps, one forward at a time on one stream (xt_set_lanes 1, {serial_ms:.3f} ms per step), run after the "
+                       f"timed region: in the timed region kernels of " + ("two batches in flight" if pipelined else f"the {lanes} parts of a batch") + " overlap")
     if rank == 0:
         T = 1 + L // (160 if args.arch == "halfresnet34" else 512)
         out = {
@@ -489,7 +519,10 @@ def main():
                        "batch_per_gpu": B, "samples_per_utt": L, "frames_per_utt": T, "resident_input_batches": len(wavs),
                        "parallelism": f"utterance-sharded x{world}" + (" + RCCL all-gather of x-vectors" if use_dist else "")},
         }
-        out["config"]["lanes"] = lanes
+        out["config"]["lanes"] = 1 if pipelined else lanes
+        out["config"]["pipeline"] = (f"{model.pipeline_depth} batches in flight: Xtractor.submit / collect (xt_forward_begin / xt_forward_end), each batch's forward on one stream "
+                                     f"of the handle; a step submits one batch and collects the one submitted {model.pipeline_depth - 1} step earlier; every batch of the timed "
+                                     f"region is collected inside it" if pipelined else "1 (one forward at a time)")
         # host budget (8 ranks share one host): wall time of the K `model(...)` calls + collectives up to the point where
         # everything is queued, per step.  The forward is ONE ctypes call into the C ABI that enqueues its ~150 launches per lane from
         # C++ (no Python per kernel); as long as this stays well below ms_per_step a rank is GPU-bound with a single host thread

@@ -82,6 +82,20 @@ int xt_forward(xt_handle* h, const float* d_wav, int64_t wav_ld, const int32_t* 
 int xt_forward_pcm16(xt_handle* h, const int16_t* d_pcm, int64_t pcm_ld, const int32_t* h_nsamples, int32_t B, int64_t L,
                      float* d_emb, float* d_logits, void* stream);
 
+/* Pipelined forwards: two WHOLE batches in flight instead of the two halves of one.  The reference driver's loop
+ * (sidekit/bin/extract_xvectors.py:130-150) is one forward at a time; a corpus is many independent batches, and two of them half a step
+ * apart use the chip better than one alone (one batch's HBM-bound first layer beside the other's MFMA-bound deep layers: 5.61 vs 5.78 ms
+ * per batch of 256 on MI355X).  xt_reserve_slots sizes `slots` (<= 4; 2 is what pays) full workspaces, each with a stream the handle
+ * owns.  xt_forward_begin queues the whole forward of a batch on slot `slot`'s stream -- behind everything queued on `stream` so far --
+ * and returns without joining; in_dtype XT_F32 (d_wav float32) or XT_I16 (16-bit PCM as in xt_forward_pcm16).  xt_forward_end makes
+ * `stream` wait for that slot's last forward: d_emb / d_logits are complete behind it.  A slot's forwards run in the order they were
+ * begun; reusing a slot before its previous batch was ended is allowed only if the caller no longer needs that batch's outputs.
+ * x-vectors are the bits xt_forward gives (tests/test_gpu_fullsize.py::test_pipelined_forwards_are_bit_identical). */
+int xt_reserve_slots(xt_handle* h, int32_t slots, int32_t max_batch, int64_t max_samples);
+int xt_forward_begin(xt_handle* h, int32_t slot, const void* d_wav, int32_t in_dtype, int64_t wav_ld, const int32_t* h_nsamples, int32_t B,
+                     int64_t L, float* d_emb, float* d_logits, void* stream);
+int xt_forward_end(xt_handle* h, int32_t slot, void* stream);
+
 /* Same, entered after the front-end (everything after xvector.py:885): the features->embedding
  * seam the parity fixtures are cut at.  d_feats float32 (B, 80, T) as MelSpecFrontEnd / MfccFrontEnd
  * return it; h_frames NULL = all T. */

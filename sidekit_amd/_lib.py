@@ -40,6 +40,9 @@ SIGNATURES = {
     "xt_reserve": (ctypes.c_int, [_P, _I32, _I64]),
     "xt_forward": (ctypes.c_int, [_P, _P, _I64, _P, _I32, _I64, _P, _P, _P]),
     "xt_forward_pcm16": (ctypes.c_int, [_P, _P, _I64, _P, _I32, _I64, _P, _P, _P]),
+    "xt_reserve_slots": (ctypes.c_int, [_P, _I32, _I32, _I64]),
+    "xt_forward_begin": (ctypes.c_int, [_P, _I32, _P, _I32, _I64, _P, _I32, _I64, _P, _P, _P]),
+    "xt_forward_end": (ctypes.c_int, [_P, _I32, _P]),
     "xt_forward_features": (ctypes.c_int, [_P, _P, _P, _I32, _I32, _P, _P, _P]),
     "xt_features": (ctypes.c_int, [_P, _P, _I64, _P, _I32, _I64, _P, _P]),
     "xt_set_norm_embedding": (ctypes.c_int, [_P, _I32]),

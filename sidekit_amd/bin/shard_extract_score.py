@@ -127,13 +127,21 @@ def main(argv=None, model=None, scoring=None):
     n_batches = (stop - start + args.batch - 1) // args.batch
     sync()
     t0 = time.perf_counter()
-    blocks = []
+    blocks, tickets = [], []
+    pipelined = dev.type == "cuda" and hasattr(model, "submit")     # two whole batches in flight (Xtractor.submit / collect)
     for k in range(n_batches):
         lo = start + k * args.batch
         hi = min(lo + args.batch, stop)
         g = torch.Generator(device=dev).manual_seed(1000 + lo)        # a batch's seed = its first utterance: independent of the rank count when shards are batch aligned
         wav = synth_batch(labels[lo:hi], freqs, amps, L, args.noise, g, dev)
-        blocks.append(model(wav, is_eval=True)[1])
+        if pipelined:
+            tickets.append(model.submit(wav))
+            if len(tickets) == model.pipeline_depth:
+                blocks.append(model.collect(tickets.pop(0))[1])
+        else:
+            blocks.append(model(wav, is_eval=True)[1])
+    while tickets:
+        blocks.append(model.collect(tickets.pop(0))[1])
     local_xv = torch.cat(blocks) if blocks else torch.empty(0, model.embedding_size, device=dev)
     sync()
     t_extract = time.perf_counter() - t0

@@ -1145,6 +1145,63 @@ int xt_forward_pcm16(xt_handle* h, const int16_t* d_pcm, int64_t pcm_ld, const i
   return forward_wav(h, d_pcm, 1, pcm_ld, h_nsamples, B, L, d_emb, d_logits, stream);
 }
 
+// ---- pipelined forwards (round 4) -----------------------------------------------------------------------------------------------
+// Two WHOLE batches in flight on two streams the handle owns beat two half batches side by side (5.61 vs 5.78 ms per batch of 256,
+// scripts/alt_streams.py): consecutive forwards run half a step apart, so one batch's HBM-bound layer 1 overlaps the other's
+// MFMA-bound layers 3-4 -- and nothing joins at the end of a call.  A slot is a full-size workspace + a stream; xt_forward_begin queues
+// the whole (serial) forward of a batch on its slot's stream behind everything queued on the caller's stream so far and returns;
+// xt_forward_end makes a stream wait for that forward.  A caller keeps `slots` batches in flight: begin(k), end(k - slots + 1), ...
+static int reserve_slot(xt_handle* h, int slot, int32_t max_batch, int64_t max_samples) {
+  Lane& lk = h->lane[slot];
+  if (!lk.stream) {
+    static const char* pe = getenv("SIDEKIT_AMD_LANE_PRIORITY");
+    int least = 0, greatest = 0;
+    SK_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    const int prio = (pe && !strcmp(pe, "normal")) ? 0 : ((pe && !strcmp(pe, "high")) ? greatest : least);
+    SK_HIP(hipStreamCreateWithPriority(&lk.stream, hipStreamNonBlocking, prio));
+    SK_HIP(hipEventCreateWithFlags(&lk.fork, hipEventDisableTiming));
+    SK_HIP(hipEventCreateWithFlags(&lk.join, hipEventDisableTiming));
+  }
+  SK_TRY(reserve_lane(h, lk, max_batch, max_samples));
+  if (slot > 0 && !lk.covers(max_batch, max_samples)) lk.reserved.push_back({max_batch, max_samples});
+  return SK_OK;
+}
+
+int xt_reserve_slots(xt_handle* h, int32_t slots, int32_t max_batch, int64_t max_samples) {
+  SK_CHECK(h && slots >= 1 && slots <= xt_handle::MAX_LANES && max_batch > 0 && max_samples > 0, SK_EARG, "xt_reserve_slots: 1 .. %d slots", xt_handle::MAX_LANES);
+  SK_HIP(hipSetDevice(h->device));
+  SK_TRY(xt_reserve(h, max_batch, max_samples));          // slot 0 = the handle's full-size workspace; records the shape
+  for (int k = 0; k < slots; ++k) SK_TRY(reserve_slot(h, k, max_batch, max_samples));
+  return SK_OK;
+}
+
+int xt_forward_begin(xt_handle* h, int32_t slot, const void* d_wav, int32_t in_dtype, int64_t wav_ld, const int32_t* h_nsamples, int32_t B, int64_t L,
+                     float* d_emb, float* d_logits, void* stream) {
+  SK_TRY(check_run(h, B, L));
+  SK_CHECK(slot >= 0 && slot < xt_handle::MAX_LANES && h->lane[slot].stream && (slot == 0 || h->lane[slot].covers(B, L)), SK_EWORKSPACE,
+           "xt_forward_begin: slot %d has no workspace for %d x %lld samples (xt_reserve_slots)", slot, B, (long long)L);
+  SK_CHECK(d_wav && d_emb && wav_ld >= L && (in_dtype == XT_F32 || in_dtype == XT_I16), SK_EARG, "xt_forward_begin: bad buffers");
+  SK_CHECK(!h->debug, SK_ESTATE, "xt_forward_begin: debug taps belong to the plain forward");
+  Lane& lk = h->lane[slot];
+  SK_HIP(hipEventRecord(lk.fork, (hipStream_t)stream));
+  SK_HIP(hipStreamWaitEvent(lk.stream, lk.fork, 0));
+  BatchMeta m;
+  int rc = lane_frontend(h, lk, d_wav, in_dtype == XT_I16 ? 1 : 0, wav_ld, h_nsamples, B, L, m, lk.stream);
+  if (rc == SK_OK) rc = lane_trunk(h, lk, m, d_emb, d_logits, lk.stream);
+  char err[sizeof(g_err)];
+  snprintf(err, sizeof(err), "%s", g_err);
+  const bool recorded = hipEventRecord(lk.join, lk.stream) == hipSuccess;   // also after an error: xt_forward_end then orders behind whatever was queued
+  if (!recorded) (void)hipStreamSynchronize(lk.stream);
+  if (rc != SK_OK) set_error("%s", err);
+  return rc;
+}
+
+int xt_forward_end(xt_handle* h, int32_t slot, void* stream) {
+  SK_CHECK(h && slot >= 0 && slot < xt_handle::MAX_LANES && h->lane[slot].stream, SK_EARG, "xt_forward_end: slot %d was never reserved", slot);
+  SK_HIP(hipStreamWaitEvent((hipStream_t)stream, h->lane[slot].join, 0));
+  return SK_OK;
+}
+
 int xt_forward_features(xt_handle* h, const float* d_feats, const int32_t* h_frames, int32_t B, int32_t T, float* d_emb,
                         float* d_logits, void* stream) {
   SK_TRY(check_run(h, B, (int64_t)(T > 0 ? T - 1 : 0) * (h ? h->fc.hop : 1)));

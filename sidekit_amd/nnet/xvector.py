@@ -66,6 +66,7 @@ class Xtractor:
         self.compute_dtype = None  # None: follow torch autocast (reduced precision -> bf16 trunk), 'fp32' or 'bf16'
         self._handles = {}
         self._reserved = {}
+        self._slot_shapes, self._tickets, self._next_slot = {}, [], 0     # pipelined forwards (submit / collect)
         self._refresh_views()
 
     # ---- torch.nn.Module look-alikes -------------------------------------------------------------
@@ -151,6 +152,51 @@ class Xtractor:
         entry = lib.xt_forward_pcm16 if x.dtype == torch.int16 else lib.xt_forward
         _lib.check(entry(h, x.data_ptr(), x.stride(0) if B > 1 else L, _ptr(lens), B, L, emb.data_ptr(),
                          logits.data_ptr() if logits is not None else None, self._stream(x)))
+        return (logits, emb) if self.loss == "aam" else emb
+
+    # ---- pipelined forwards: two whole batches in flight (xt_forward_begin / xt_forward_end) ---------------------------------------
+    pipeline_depth = 2
+
+    def submit(self, x, lengths=None, norm_embedding=True):
+        """Queue ``forward(x, is_eval=True)`` WITHOUT waiting for it on the caller's stream and return a ticket for :meth:`collect`.
+
+        The reference driver runs one forward at a time (``extract_xvectors.py:130-150``); a corpus is many independent batches, and keeping
+        ``pipeline_depth`` (2) of them in flight -- each on a stream the handle owns, half a step apart -- uses the chip better than the two
+        halves of one batch side by side (5.61 vs 5.78 ms per batch of 256).  Tickets must be collected in submission order; at most
+        ``pipeline_depth`` may be outstanding.  The x-vectors are the bits ``forward`` returns."""
+        x = self._check_input(x, pcm16_ok=True)
+        B, L = x.shape
+        h = self._handle()
+        key = next(k for k, v in self._handles.items() if v is h)
+        lib = _lib.lib()
+        shapes = self._slot_shapes.setdefault(key, [])
+        if not any(b >= B and l >= L for b, l in shapes):
+            with torch.cuda.device(self.device):
+                torch.cuda.synchronize(self.device)
+                _lib.check(lib.xt_reserve_slots(h, self.pipeline_depth, B, L))
+            shapes[:] = [(b, l) for b, l in shapes if not (b <= B and l <= L)] + [(B, L)]
+            self._reserved[key] = [(b, l) for b, l in self._reserved[key] if not (b <= B and l <= L)] + [(B, L)]
+        if len(self._tickets) >= self.pipeline_depth:
+            raise RuntimeError(f"submit: {self.pipeline_depth} batches are already in flight -- collect() the oldest first")
+        _lib.check(lib.xt_set_norm_embedding(h, 1 if norm_embedding else 0))
+        emb = torch.empty((B, self.embedding_size), dtype=torch.float32, device=x.device)
+        logits = torch.empty((B, int(self.speaker_number)), dtype=torch.float32, device=x.device) if self.loss == "aam" else None
+        lens = self._lengths(lengths, B, L)
+        slot = self._next_slot
+        _lib.check(lib.xt_forward_begin(h, slot, x.data_ptr(), _lib.XT_I16 if x.dtype == torch.int16 else _lib.XT_F32,
+                                        x.stride(0) if B > 1 else L, _ptr(lens), B, L, emb.data_ptr(),
+                                        logits.data_ptr() if logits is not None else None, self._stream(x)))
+        self._next_slot = (slot + 1) % self.pipeline_depth
+        ticket = (h, slot, x, logits, emb)        # x is kept alive until the forward that reads it has been waited for
+        self._tickets.append(ticket)
+        return ticket
+
+    def collect(self, ticket):
+        """Make the current stream wait for the oldest submitted batch and return what ``forward`` returns for it."""
+        if not self._tickets or self._tickets[0] is not ticket:
+            raise RuntimeError("collect: tickets are collected in submission order")
+        h, slot, x, logits, emb = self._tickets.pop(0)
+        _lib.check(_lib.lib().xt_forward_end(h, slot, self._stream(emb)))
         return (logits, emb) if self.loss == "aam" else emb
 
     def forward_features(self, feats, frames=None, norm_embedding=True):
@@ -320,6 +366,7 @@ class Xtractor:
             for h in self._handles.values():
                 lib.xt_destroy(h)
         self._handles, self._reserved = {}, {}
+        self._slot_shapes, self._tickets, self._next_slot = {}, [], 0
 
     def __del__(self):
         try:

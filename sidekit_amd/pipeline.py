@@ -216,6 +216,7 @@ class StreamingExtractor:
         self.cuda = self.device.type == "cuda"
         self.ring = [_Staging(self.device) for _ in range(self.pending + self.stage_ahead + 1)]
         self.copy_stream = torch.cuda.Stream(self.device) if self.cuda else None
+        self.pipelined = self.cuda and hasattr(model, "submit")   # two whole batches in flight (Xtractor.submit / collect)
         self.stats = {"utterances": 0, "batches": 0, "samples": 0, "padded_samples": 0, "native_reads": 0}
 
     def _resample(self, sample, rate):
@@ -287,19 +288,31 @@ class StreamingExtractor:
                 dev.copy_(host, non_blocking=True)
                 slot.copied.record(self.copy_stream)
             compute.wait_event(slot.copied)
-        with torch.no_grad():                                   # int16 rows go in as they are: the front-end kernel widens them in its load
-            out = self.model(dev, is_eval=True, norm_embedding=self.norm_embedding, lengths=lens)
-        emb = out[1] if isinstance(out, tuple) else out
-        oh = slot.out(max(rows, self.batch_size), emb.shape[1])
-        oh[:rows].copy_(emb, non_blocking=self.cuda)
-        if self.cuda:
-            slot.done.record(torch.cuda.current_stream(self.device))
         self.stats["utterances"] += rows
         self.stats["batches"] += 1
         self.stats["samples"] += sum(lens)
         self.stats["padded_samples"] += rows * cols
         self.stats["native_reads"] += n_native
-        return slot, [it.key for it in items], oh, rows
+        keys = [it.key for it in items]
+        with torch.no_grad():                                   # int16 rows go in as they are: the front-end kernel widens them in its load
+            if self.pipelined:
+                # the batch's whole forward is queued on one of the handle's slot streams and NOT waited for: the next batch is submitted
+                # before this one is collected, so two batches are in flight, half a step apart (Xtractor.submit)
+                return slot, keys, self.model.submit(dev, lengths=lens, norm_embedding=self.norm_embedding), rows
+            out = self.model(dev, is_eval=True, norm_embedding=self.norm_embedding, lengths=lens)
+        return self._read_back(slot, keys, out, rows)
+
+    def _finish(self, slot, keys, ticket, rows):
+        """Second half of a pipelined launch: the compute stream waits for the batch's forward, then queues the read-back."""
+        return self._read_back(slot, keys, self.model.collect(ticket), rows)
+
+    def _read_back(self, slot, keys, out, rows):
+        emb = out[1] if isinstance(out, tuple) else out
+        oh = slot.out(max(rows, self.batch_size), emb.shape[1])
+        oh[:rows].copy_(emb, non_blocking=self.cuda)
+        if self.cuda:
+            slot.done.record(torch.cuda.current_stream(self.device))
+        return slot, keys, oh, rows
 
     def _collect(self, slot, keys, oh, rows):
         if self.cuda:
@@ -319,10 +332,24 @@ class StreamingExtractor:
             for s in self.ring:
                 s.done.record(torch.cuda.current_stream(self.device))   # "previous batch" of a fresh slot
 
+        inflight = collections.deque()        # pipelined: (slot, keys, ticket, rows) submitted, forward not yet waited for
+        depth = getattr(self.model, "pipeline_depth", 2) if self.pipelined else 1
+
+        def finish_oldest():
+            launched.append(self._finish(*inflight.popleft()))
+
         def launch_oldest():
-            launched.append(self._launch(*staged.popleft().result()))
+            entry = self._launch(*staged.popleft().result())
+            if not self.pipelined:
+                launched.append(entry)
+                return
+            inflight.append(entry)
+            while len(inflight) >= depth:       # submit(k), then collect(k - depth + 1): `depth` forwards were in flight meanwhile
+                finish_oldest()
 
         def collect_oldest():
+            if not launched:
+                finish_oldest()
             slot, keys, oh, rows = launched.popleft()
             yield from self._collect(slot, keys, oh, rows)
             free.append(slot)
@@ -336,7 +363,7 @@ class StreamingExtractor:
                 for idx in plan_batches([it.length for it in items], self.batch_size, self.max_samples_per_batch):
                     batch = [items[i] for i in idx]
                     while not free:                             # every slot is staged, in flight or waiting to be read back
-                        if launched:
+                        if launched or inflight:
                             yield from collect_oldest()
                         else:
                             launch_oldest()
@@ -347,9 +374,9 @@ class StreamingExtractor:
                     staged.append(stager.submit(self._stage, slot, batch, host, dev, as_int16))
                     while staged and (staged[0].done() or len(staged) > self.stage_ahead):
                         launch_oldest()
-                        while len(launched) > self.pending:
+                        while len(launched) + len(inflight) > self.pending:
                             yield from collect_oldest()
             while staged:
                 launch_oldest()
-            while launched:
+            while launched or inflight:
                 yield from collect_oldest()

@@ -67,6 +67,7 @@ def test_bench_one_rank_over_rccl_matches_the_plain_run():
     d = _json_line(_torchrun(common))
     p = _json_line(_plain(common))
     assert "RCCL all-gather" in d["config"]["parallelism"] and "RCCL" not in p["config"]["parallelism"]
+    assert "2 batches in flight" in d["config"]["pipeline"] and d["config"]["lanes"] == 1
     assert d["n_gpus"] == 1 and d["steps"] == 20 and d["dtype"] == "bf16" and d["scaling"] == "weak"
     assert d["value"] > 0 and abs(d["value"] - 256 * 1000.0 / d["ms_per_step"]) / d["value"] < 1e-6
     ratio = d["ms_per_step"] / p["ms_per_step"]

@@ -282,3 +282,62 @@ def test_normalize_rows_matches_torch(gpu):
     assert float((got - want).abs().max()) < 2e-7
     x2 = torch.randn(33, 100)                        # a dimension that is not a multiple of 4 or 64
     assert float((normalize_rows_device(x2).cpu() - torch.nn.functional.normalize(x2, dim=1)).abs().max()) < 2e-7
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp32"])
+def test_pipelined_forwards_are_bit_identical(gpu, dtype):
+    """Xtractor.submit / collect (xt_forward_begin / xt_forward_end): two whole batches in flight on the handle's two slot streams give the
+    x-vectors and logits of the plain forward, bit for bit -- uniform, ragged, PCM16, a partial batch after a full one, interleaved with plain
+    forwards on the same handle -- tickets come back in order, and a third submit without a collect is refused."""
+    m = Xtractor(64, model_archi="halfresnet34", loss="aam", seed=12).to(gpu).eval()
+    m.compute_dtype = dtype
+    g = torch.Generator(device="cuda").manual_seed(21)
+    batches = []
+    for B, L, ragged, pcm in ((256, 32000, False, False), (200, 24000, True, False), (256, 32000, False, True), (37, 48000, True, False), (256, 32000, False, False)):
+        wav = 0.1 * torch.randn(B, L, device="cuda", generator=g)
+        if pcm:
+            wav = (wav * 32768.0).round().clamp(-32768, 32767).to(torch.int16)
+        lens = torch.randint(L // 3, L + 1, (B,), generator=torch.Generator().manual_seed(B + L)).tolist() if ragged else None
+        batches.append((wav, lens))
+    refs = [tuple(t.clone() for t in m(w, is_eval=True, lengths=l)) for w, l in batches]
+    for rep in range(3 if dtype == "bf16" else 1):
+        tickets, outs = [], []
+        for i, (w, l) in enumerate(batches):
+            tickets.append(m.submit(w, lengths=l))
+            if len(tickets) == 2:
+                outs.append(m.collect(tickets.pop(0)))
+            if i == 2:                                           # a plain forward between two submits: it shares slot 0's stream order
+                lg, e = m(batches[0][0], is_eval=True)
+                assert torch.equal(e, refs[0][1])
+        while tickets:
+            outs.append(m.collect(tickets.pop(0)))
+        torch.cuda.synchronize()
+        for (lg, e), (rlg, re_) in zip(outs, refs):
+            assert torch.equal(e, re_) and torch.equal(lg, rlg)
+    t1, t2 = m.submit(batches[0][0]), m.submit(batches[0][0])
+    with pytest.raises(RuntimeError):
+        m.submit(batches[0][0])                                   # two are in flight
+    with pytest.raises(RuntimeError):
+        m.collect(t2)                                             # out of order
+    assert torch.equal(m.collect(t1)[1], refs[0][1]) and torch.equal(m.collect(t2)[1], refs[0][1])
+    bad = [32000] * 256
+    bad[5] = 100
+    with pytest.raises(ValueError):
+        m.submit(batches[0][0], lengths=bad)                      # refused before anything is queued
+    assert torch.equal(m.collect(m.submit(batches[0][0]))[1], refs[0][1])
+
+
+def test_pipelined_forwards_tdnn(gpu):
+    """The same for the TDNN x-vector (ragged rows, fp32): submit / collect against the plain forward."""
+    m = Xtractor(64, model_archi="xvector", loss="aam", seed=13).to(gpu).eval()
+    g = torch.Generator(device="cuda").manual_seed(22)
+    wav = 0.1 * torch.randn(96, 64000, device="cuda", generator=g)
+    lens = torch.randint(32000, 64001, (96,), generator=torch.Generator().manual_seed(3)).tolist()
+    ref_a, ref_b = m(wav, is_eval=True, lengths=lens)[1].clone(), m(wav[:40], is_eval=True)[1].clone()
+    for _ in range(2):
+        t1 = m.submit(wav, lengths=lens)
+        t2 = m.submit(wav[:40])
+        assert torch.equal(m.collect(t1)[1], ref_a)
+        t3 = m.submit(wav, lengths=lens)
+        assert torch.equal(m.collect(t2)[1], ref_b) and torch.equal(m.collect(t3)[1], ref_a)
+    torch.cuda.synchronize()
