@@ -199,6 +199,12 @@ class Xtractor:
         _lib.check(_lib.lib().xt_forward_end(h, slot, self._stream(emb)))
         return (logits, emb) if self.loss == "aam" else emb
 
+    def discard_pending(self):
+        """Collect (and drop) every outstanding ticket: the state after this is that of a model nothing was submitted to.  For callers that
+        abandon a pipelined loop half way (an exception between ``submit`` and ``collect``)."""
+        while self._tickets:
+            self.collect(self._tickets[0])
+
     def forward_features(self, feats, frames=None, norm_embedding=True):
         """Everything after ``xvector.py:885``: ``feats`` is the ``(B, 80, T)`` front-end output."""
         feats = self._check_input(feats, dims=3)

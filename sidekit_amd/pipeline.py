@@ -354,6 +354,14 @@ class StreamingExtractor:
             yield from self._collect(slot, keys, oh, rows)
             free.append(slot)
 
+        try:
+            yield from self._run(entries, span, free, staged, launched, inflight, launch_oldest, collect_oldest)
+        finally:
+            if self.pipelined and inflight:       # abandoned half way (an exception, or the consumer stopped iterating): leave no ticket behind
+                inflight.clear()
+                self.model.discard_pending()
+
+    def _run(self, entries, span, free, staged, launched, inflight, launch_oldest, collect_oldest):
         with concurrent.futures.ThreadPoolExecutor(self.workers) as pool, concurrent.futures.ThreadPoolExecutor(self.stage_ahead) as stager:
             while True:
                 chunk = list(itertools.islice(entries, span))
