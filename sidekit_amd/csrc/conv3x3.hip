@@ -1051,7 +1051,11 @@ static int launch_cfg(const ConvArgs& a, hipStream_t st) {
   // weight-resident shapes: just the workgroups the chip holds at once (LDS and the compiled-for occupancy), persistent
   constexpr int NWV = C::WM * C::WN;
   const int occ = ((a.sc_wpack && !a.sc_in) ? 1 : C::OCC) * 4 / NWV, by_lds = 160 * 1024 / C::LDS;   // the fused-shortcut kernels are compiled for one wave per SIMD
-  const int resident_wgs = cu_count() * (occ < by_lds ? (occ > 0 ? occ : 1) : by_lds);
+  // persist_cap (pipelined forwards, xt_forward_begin): a persistent shape takes fewer workgroups per CU than fit, so that the OTHER batch in flight finds room beside it -- with
+  // all of a CU's registers and LDS held by a persistent layer-1 grid the other batch's kernels could only wait for it to end.  One per CU: 5.59 vs 5.63 ms per step with two batches
+  // in flight (and 6.57 vs 5.92 ms for a forward on its own, which is why it is not the default of the plain forward).
+  const int per_cu = (occ < by_lds ? (occ > 0 ? occ : 1) : by_lds);
+  const int resident_wgs = cu_count() * ((a.persist_cap > 0 && a.persist_cap < per_cu) ? a.persist_cap : per_cu);
   constexpr int NY = C::COUT / C::NT;   // workgroups per work item (output-channel split): folded into a 1-D grid, see the kernel
   static_assert(NY == 1 || !C::RESIDENT, "persistent shapes cover all output channels");
   dim3 grid((unsigned)(NY > 1 ? cdiv(nwork, 8) * 8 * NY : ((C::RESIDENT && !(a.dbg & 8) && nwork > resident_wgs) ? resident_wgs : nwork)), 1);

@@ -49,6 +49,7 @@ struct ConvArgs {
   int halvings_in;     // stride-2 stages between the features and this conv's input
   int B, Hin, Hout;    // allocated rows of in / out
   int relu;
+  int persist_cap;     // > 0: at most this many workgroups per CU for the persistent (weight-resident) shapes, see launch_cfg
   unsigned long long* stamps;  // diagnostics only: per-workgroup s_memtime stamps at the phase boundaries (8 per block), or nullptr
   int dbg;             // diagnostics only (sk_bench_conv): bit0 skip stores, bit1 skip MFMA loop, bit2 skip staging
 };

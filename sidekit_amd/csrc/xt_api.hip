@@ -79,6 +79,7 @@ struct Lane {
   int ring_cur = 0;
   hipStream_t stream = nullptr;        // lanes 1 .. n-1 only: the stream that part of the batch runs on
   hipEvent_t fork = nullptr, join = nullptr;
+  int persist_cap = 0;                 // set by xt_forward_begin: persistent convolution grids leave room for the other batch in flight (conv3x3.hip, launch_cfg)
   std::vector<std::pair<int, int64_t>> reserved;   // side lanes: the (utterances, samples) shapes this lane's workspace has been sized for
   bool covers(int B, int64_t L) const {
     for (auto& r : reserved) if (r.first >= B && r.second >= L) return true;
@@ -683,7 +684,7 @@ static int half_from_feats(xt_handle* h, Lane& ln, const float* feats, long sb, 
     const int wout = 80 >> li;
     ConvArgs a;
     memset(&a, 0, sizeof(a));
-    a.lens = m.lens; a.B = B; a.zeros = h->d_zeros;
+    a.lens = m.lens; a.B = B; a.zeros = h->d_zeros; a.persist_cap = ln.persist_cap;
     // conv1 + bn1 + relu -> O1, leaving the sums the block's SE gate is derived from
     a.in = X; a.wpack = b.c1.wpack; a.scale = b.c1.scale; a.shift = b.c1.shift; a.out = O1;
     a.se_part = (float*)ln.ws_se.p; a.col_part = (float*)ln.ws_col.p; a.edge = (float*)ln.ws_edge.p;
@@ -1097,6 +1098,7 @@ static int forward_wav(xt_handle* h, const void* d_wav, int pcm16, int64_t wav_l
   };
   while (n > 1 && !parts_fit(n)) --n;
   BatchMeta m0;
+  for (int k = 0; k < xt_handle::MAX_LANES; ++k) h->lane[k].persist_cap = 0;
   if (n == 1) {
     SK_TRY(lane_frontend(h, l0, d_wav, pcm16, wav_ld, h_nsamples, B, L, m0, st));
     return lane_trunk(h, l0, m0, d_emb, d_logits, st);
@@ -1185,6 +1187,8 @@ int xt_forward_begin(xt_handle* h, int32_t slot, const void* d_wav, int32_t in_d
   Lane& lk = h->lane[slot];
   SK_HIP(hipEventRecord(lk.fork, (hipStream_t)stream));
   SK_HIP(hipStreamWaitEvent(lk.stream, lk.fork, 0));
+  static const int cap = getenv("SIDEKIT_AMD_SLOT_PERSIST_CAP") ? atoi(getenv("SIDEKIT_AMD_SLOT_PERSIST_CAP")) : 1;
+  lk.persist_cap = cap;
   BatchMeta m;
   int rc = lane_frontend(h, lk, d_wav, in_dtype == XT_I16 ? 1 : 0, wav_ld, h_nsamples, B, L, m, lk.stream);
   if (rc == SK_OK) rc = lane_trunk(h, lk, m, d_emb, d_logits, lk.stream);
@@ -1209,6 +1213,7 @@ int xt_forward_features(xt_handle* h, const float* d_feats, const int32_t* h_fra
   hipStream_t st = (hipStream_t)stream;
   BatchMeta m;
   Lane& ln = h->lane[0];
+  ln.persist_cap = 0;
   SK_TRY(make_meta(h, ln, h_frames, B, T, false, m, st));
   if (h->cfg.arch == XT_ARCH_HALFRESNET34) {
     m.T = T;  // rows are addressed through the caller's (B, 80, T) strides
