@@ -1100,6 +1100,9 @@ static int forward_wav(xt_handle* h, const void* d_wav, int pcm16, int64_t wav_l
   BatchMeta m0;
   for (int k = 0; k < xt_handle::MAX_LANES; ++k) h->lane[k].persist_cap = 0;
   if (n == 1) {
+    // an unsplit forward runs on the CALLER's stream in lane 0's workspace: a pipelined batch (xt_forward_begin, slot 0) may still be running there on
+    // lane 0's own stream -- order behind it (found by scripts/soak_pipelined.py: a small plain forward between two submits raced with slot 0)
+    if (l0.stream) SK_HIP(hipStreamWaitEvent(st, l0.join, 0));
     SK_TRY(lane_frontend(h, l0, d_wav, pcm16, wav_ld, h_nsamples, B, L, m0, st));
     return lane_trunk(h, l0, m0, d_emb, d_logits, st);
   }
@@ -1214,6 +1217,7 @@ int xt_forward_features(xt_handle* h, const float* d_feats, const int32_t* h_fra
   BatchMeta m;
   Lane& ln = h->lane[0];
   ln.persist_cap = 0;
+  if (ln.stream) SK_HIP(hipStreamWaitEvent(st, ln.join, 0));   // lane 0's workspace: behind whatever its own stream still runs (forward_wav)
   SK_TRY(make_meta(h, ln, h_frames, B, T, false, m, st));
   if (h->cfg.arch == XT_ARCH_HALFRESNET34) {
     m.T = T;  // rows are addressed through the caller's (B, 80, T) strides
@@ -1233,6 +1237,7 @@ int xt_features(xt_handle* h, const float* d_wav, int64_t wav_ld, const int32_t*
   hipStream_t st = (hipStream_t)stream;
   BatchMeta m;
   Lane& ln = h->lane[0];
+  if (ln.stream) SK_HIP(hipStreamWaitEvent(st, ln.join, 0));   // lane 0's workspace: behind whatever its own stream still runs (forward_wav)
   SK_TRY(make_meta(h, ln, h_nsamples, B, L, true, m, st));
   float* feat = (float*)ln.ws_feat.p;
   SK_TRY(frontend_rows(h, ln, d_wav, 0, wav_ld, m, feat, st));

@@ -341,3 +341,15 @@ def test_pipelined_forwards_tdnn(gpu):
         t3 = m.submit(wav, lengths=lens)
         assert torch.equal(m.collect(t2)[1], ref_b) and torch.equal(m.collect(t3)[1], ref_a)
     torch.cuda.synchronize()
+
+
+def test_pipelined_and_plain_forwards_interleaved_at_random(gpu):
+    """scripts/soak_pipelined.py as a test: random batch shapes (1..300 utterances, 0.3..6 s, ragged / uniform, float32 / PCM16) through submit / collect,
+    interleaved at random with plain forwards -- split ones and small unsplit ones, which run on the CALLER's stream in slot 0's workspace (the soak found
+    such a forward racing with a pipelined batch still running there; it now orders behind lane 0's stream) -- against a one-at-a-time reference model."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("soak_pipelined", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "soak_pipelined.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.main(250, verbose=False) == 0
