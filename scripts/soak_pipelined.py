@@ -7,12 +7,12 @@ import torch
 from sidekit_amd.nnet import Xtractor
 
 
-def main(n_iter=200, verbose=True):
+def main(n_iter=200, verbose=True, arch="halfresnet34", dtype="bf16"):
     """-> number of mismatching results (0 = every pipelined / plain forward equals the one-at-a-time reference, bit for bit)."""
     dev = torch.device("cuda", 0)
-    a = Xtractor(64, model_archi="halfresnet34", loss="aam", seed=99).to(dev).eval()
-    b = Xtractor(64, model_archi="halfresnet34", loss="aam", seed=99).to(dev).eval()
-    a.compute_dtype = b.compute_dtype = "bf16"
+    a = Xtractor(64, model_archi=arch, loss="aam", seed=99).to(dev).eval()
+    b = Xtractor(64, model_archi=arch, loss="aam", seed=99).to(dev).eval()
+    a.compute_dtype = b.compute_dtype = dtype
     b.set_lanes(1)
     rnd = random.Random(5)
     g = torch.Generator(device=dev).manual_seed(5)
@@ -27,13 +27,13 @@ def main(n_iter=200, verbose=True):
 
     for it in range(n_iter):
         B = rnd.choice([1, 3, 17, 64, 127, 128, 129, 200, 256, 300])
-        L = rnd.choice([4800, 16000, 33333, 64000, 96000])
+        L = rnd.choice([16000, 33333, 64000, 96000] if arch == "xvector" else [4800, 16000, 33333, 64000, 96000])
         if B * L > 256 * 64000:
             B = max(1, 256 * 64000 // L)
         wav = 0.1 * torch.randn(B, L, device=dev, generator=g)
         if rnd.random() < 0.3:
             wav = (wav * 32768.0).round().clamp(-32768, 32767).to(torch.int16)
-        lens = [rnd.randint(max(600, L // 3), L) for _ in range(B)] if rnd.random() < 0.5 else None
+        lens = [rnd.randint(max(8000 if arch == "xvector" else 600, L // 3), L) for _ in range(B)] if rnd.random() < 0.5 else None
         want = tuple(t.clone() for t in b(wav, is_eval=True, lengths=lens))
         if rnd.random() < 0.7:
             pend.append((a.submit(wav, lengths=lens), want, (B, L)))
@@ -54,4 +54,4 @@ def main(n_iter=200, verbose=True):
 
 
 if __name__ == "__main__":
-    sys.exit(1 if main(int(sys.argv[1]) if len(sys.argv) > 1 else 200) else 0)
+    sys.exit(1 if main(int(sys.argv[1]) if len(sys.argv) > 1 else 200, True, *(sys.argv[2:4])) else 0)
