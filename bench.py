@@ -449,7 +449,7 @@ def main():
     # it (picked from the last warmup steps, every class bracketed).  (2) Two lanes: the lanes are serialised AFTER the timed
     # region, 3 steps with every class bracketed give the per-class table, K more steps with the two largest classes bracketed
     # give the roofline object.
-    per_class, focus, n_prof, prof, serial_ms = None, None, 0, None, None
+    per_class, focus, n_prof, prof, serial_ms, one_at_a_time_ms = None, None, 0, None, None, None
     profile = not args.no_profile
 
     def pick_focus(prof_w, n):
@@ -505,6 +505,15 @@ def main():
         prof = model.get_profile(reset=True)
         model.set_profile(False)
         model.set_lanes(lanes)
+        if pipelined:   # for comparison: the same K steps issued one forward at a time (the split of a batch over `lanes` streams), this rank alone
+            for _ in range(2):
+                step()
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            torch.cuda.synchronize(dev)
+            one_at_a_time_ms = (time.perf_counter() - t0) / args.steps * 1e3
         measured_in = (f"a second region of {args.steps} steps, one forward at a time on one stream (xt_set_lanes 1, {serial_ms:.3f} ms per step), run after the "
                        f"timed region: in the timed region kernels of " + ("two batches in flight" if pipelined else f"the {lanes} parts of a batch") + " overlap")
     if rank == 0:
@@ -528,6 +537,9 @@ def main():
         # C++ (no Python per kernel); as long as this stays well below ms_per_step a rank is GPU-bound with a single host thread
         out["host_enqueue_ms_per_step"] = host_enqueue[0] / args.steps * 1e3
         out["host_enqueue_frac"] = host_enqueue[0] / dt
+        if one_at_a_time_ms is not None:
+            out["one_forward_at_a_time"] = {"ms_per_step": one_at_a_time_ms, "value": B * 1e3 / one_at_a_time_ms, "lanes": lanes,
+                                            "note": "the same batches issued through Xtractor.forward, one at a time (the batch split over `lanes` streams), measured on rank 0 after the timed region"}
         if profile and prof is not None:
             if args.arch == "halfresnet34":
                 r = roofline(prof, B, T, dtype, per_class)
