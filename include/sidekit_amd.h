@@ -10,8 +10,14 @@
  *     available from xt_last_error() (thread-local).  No exception crosses the ABI.
  *   - `d_` pointers are device (HIP) pointers owned by the caller, `h_` pointers are host memory.
  *   - `stream` is a hipStream_t (NULL = default stream); calls are asynchronous on that stream.
- *   - a handle is bound to the device current at xt_create() and is not thread-safe; handles on
- *     different devices are independent (one process per GPU).
+ *   - a handle is bound to the device current at xt_create(); handles on different devices are independent (one process per GPU).
+ *   - streams: consecutive calls on one handle may arrive on DIFFERENT streams.  The handle's workspaces are reused from call to call;
+ *     the library orders that reuse itself: every call that touches a workspace (xt_forward*, xt_forward_begin, xt_forward_features,
+ *     xt_features) records an event on the stream it was given, and a call that arrives on another stream first makes its stream wait for
+ *     that event and for every batch still in flight on the handle's own streams.  (The caller still orders its own buffers: d_wav must be
+ *     ready, and d_emb is complete, in the order of the stream passed.)
+ *   - threads: one host thread at a time per handle.  A second thread that enters a handle while another is inside gets SK_ESTATE and
+ *     nothing is enqueued; use one handle per driving thread (the reference, too, drives a model from one thread: SURVEY 8b).
  */
 #ifndef SIDEKIT_AMD_H
 #define SIDEKIT_AMD_H
@@ -27,7 +33,7 @@ extern "C" {
 #define SK_ESHAPE (-2)     /* shape / key mismatch    -> RuntimeError (as torch load_state_dict) */
 #define SK_EHIP (-3)       /* HIP runtime error       -> RuntimeError                            */
 #define SK_EWORKSPACE (-4) /* batch exceeds xt_reserve -> RuntimeError                           */
-#define SK_ESTATE (-5)     /* call order (e.g. forward before finalize) -> RuntimeError          */
+#define SK_ESTATE (-5)     /* call order (e.g. forward before finalize), concurrent entry -> RuntimeError */
 
 enum { XT_ARCH_HALFRESNET34 = 0, XT_ARCH_TDNN = 1 };
 enum { XT_F32 = 0, XT_BF16 = 1, XT_F64 = 2, XT_I64 = 3, XT_I16 = 4 };

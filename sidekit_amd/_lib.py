@@ -11,6 +11,12 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libsidekit_amd.so")
 if os.environ.get("SIDEKIT_AMD_LIB"):   # tuning aid: another build of the SAME library (A/B runs of kernel variants); never a different backend
     LIB_PATH = os.path.abspath(os.environ["SIDEKIT_AMD_LIB"])
+    import warnings
+    warnings.warn(f"SIDEKIT_AMD_LIB is set: loading {LIB_PATH} instead of the shipped csrc/libsidekit_amd.so (A/B tuning aid)", RuntimeWarning)
+for _tuning in ("SIDEKIT_AMD_SHAPE_MAP", "SIDEKIT_AMD_CONV_DBG"):
+    if os.environ.get(_tuning):
+        import warnings
+        warnings.warn(f"{_tuning}={os.environ[_tuning]!r} is set: kernels differ from the product configuration (A/B tuning aid)", RuntimeWarning)
 
 SK_OK, SK_EARG, SK_ESHAPE, SK_EHIP, SK_EWORKSPACE, SK_ESTATE = 0, -1, -2, -3, -4, -5
 XT_ARCH_HALFRESNET34, XT_ARCH_TDNN = 0, 1

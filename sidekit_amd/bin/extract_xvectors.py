@@ -21,9 +21,9 @@ import scipy.io.wavfile
 import torch
 import torch.distributed as dist
 
-from ..kaldi_io import ArkScpWriter, read_scp
+from ..kaldi_io import ArkScpWriter, OrderedArkWriter, read_scp
 from ..nnet.xvector import Xtractor
-from ..pipeline import StreamingExtractor
+from ..pipeline import StreamingExtractor, host_workers
 from ..sharding import gather_xvectors, shard_range
 
 
@@ -70,7 +70,7 @@ def load_model(model_path, device):
     return xtractor.to(device).eval(), archi
 
 
-def precheck(xtractor, entries, sample_rate, workers=8):
+def precheck(xtractor, entries, sample_rate, workers=4):
     """Header-only pass over the plain files of ``entries`` (``cmd |`` pipes cannot be probed): raises ``IOError`` for a file that
     cannot be opened and ``ValueError`` for one too short for the front-end's reflect padding (``n_fft / 2 < samples``, what
     ``torch.stft(center=True)`` demands in the reference) at the model's rate."""
@@ -90,10 +90,14 @@ def precheck(xtractor, entries, sample_rate, workers=8):
 
 @torch.no_grad()
 def main(xtractor, wav_scp, out_file, device, sample_rate=16000, out_file_spk="", spk2utt_file="", batch_size=64, dtype="fp32",
-         workers=8, window=8):
+         workers=None, window=8, gather_always=False):
     """One process: the whole wav.scp.  Under ``torch.distributed.run`` (one process per GPU, an initialised process group):
     every rank streams the contiguous shard ``shard_range(len(wav.scp), rank, world)``, the ``(N_r, E)`` blocks are gathered once
-    (``gather_xvectors``: RCCL all-gather, ragged counts) and rank 0 writes the ark / scp files in wav.scp order."""
+    (``gather_xvectors``: RCCL all-gather, ragged counts) and rank 0 writes the ark / scp files in wav.scp order.
+    With ONE rank the files are written incrementally as in a plain run (``gather_always`` takes the collective path all the same: the
+    rehearsal of the N-rank code on a one-GPU box).  ``workers=None``: this rank's share of the host cores (``host_workers``)."""
+    if workers is None:
+        workers = host_workers()
     utt2wav = read_wav_scp(wav_scp)
     xtractor.compute_dtype = dtype
     keys = list(utt2wav)
@@ -109,20 +113,17 @@ def main(xtractor, wav_scp, out_file, device, sample_rate=16000, out_file_spk=""
     stream = StreamingExtractor(xtractor, batch_size=batch_size, window=window, workers=workers, sample_rate=sample_rate)
     results = stream.run((key, ' '.join(utt2wav[key])) for key in keys[lo:hi])
     out_ark = os.path.realpath(os.path.join(os.path.dirname(out_file), os.path.splitext(os.path.basename(out_file))[0]))
-    sharded = dist.is_initialized()   # under torch.distributed.run, also with ONE rank: the RCCL gather path is the one that runs
+    sharded = dist.is_initialized() and (world > 1 or gather_always)
     if not sharded:
-        # one process: every x-vector goes to the ark as its batch comes back (the reference writes per utterance, :147), the scp
-        # grows beside it in arrival order (flushed per batch: what was extracted survives an interruption) and is rewritten in
-        # wav.scp order at the end
-        lines = {}
-        with ArkScpWriter(f"{out_ark}.ark", os.path.realpath(out_file)) as writer:
+        # one process (or one rank): the ark holds its records in wav.scp order like the reference's (extract_xvectors.py:120,147) although
+        # batches come back length-sorted -- a (1, E) record's size follows from its key, so every x-vector is written at its final offset
+        # the moment its batch arrives (flushed per batch: what was extracted survives an interruption); the scp grows in arrival order
+        # beside it and is rewritten in wav.scp order at the end
+        with OrderedArkWriter(f"{out_ark}.ark", os.path.realpath(out_file), keys, xtractor.embedding_size) as writer:
             for n, (key, vec) in enumerate(results):
-                lines[key] = writer(key, vec)       # (1, E) float matrix per key, what the reference writes
+                writer(key, vec)
                 if n % batch_size == batch_size - 1:
                     writer.flush()
-        with open(os.path.realpath(out_file), "w") as f:
-            for key in utt2wav:
-                f.write(lines[key])
         vecs = None
     mine = dict(results) if sharded else None
     if sharded:
@@ -162,7 +163,9 @@ def cli(argv=None):
     parser.add_argument("--device", default="cuda", type=str)
     parser.add_argument("--batch-size", type=int, default=64)
     parser.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"])
-    parser.add_argument("--workers", type=int, default=8, help="wav decoding threads")
+    parser.add_argument("--workers", type=int, default=0, help="wav decoding threads (0: this rank's share of the host cores, at most 8)")
+    parser.add_argument("--gather-always", action="store_true", help="with one rank under torch.distributed.run: still gather through the collective and let rank 0 "
+                        "write at the end (rehearsal of the N-rank path on a one-GPU box) instead of writing incrementally")
     parser.add_argument("--window", type=int, default=8, help="utterances are length-sorted inside windows of this many batches")
     args = parser.parse_args(argv)
     assert os.path.isfile(args.model), "NO SUCH FILE: %s" % args.model
@@ -174,7 +177,9 @@ def cli(argv=None):
         assert os.path.isdir(os.path.dirname(args.out_spk_scp)), "NO SUCH DIRECTORY: %s" % args.out_spk_scp
         assert os.path.isfile(args.spk2utt_file), "NO SUCH FILE: %s" % args.spk2utt_file
     device = args.device.strip().lower()
-    if "RANK" in os.environ:   # python -m torch.distributed.run --nproc-per-node N -m sidekit_amd.bin.extract_xvectors ...
+    # python -m torch.distributed.run --nproc-per-node N -m sidekit_amd.bin.extract_xvectors ...: the launcher's whole environment, not a
+    # stray RANK a batch system exported (a rendezvous without MASTER_ADDR / MASTER_PORT fails or hangs)
+    if all(k in os.environ for k in ("RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")):
         local = int(os.environ.get("LOCAL_RANK", "0"))
         if device.startswith("cuda"):
             os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -184,7 +189,7 @@ def cli(argv=None):
         else:
             dist.init_process_group("gloo")
     xtractor, _ = load_model(args.model, device)
-    main(xtractor, args.wav_scp, args.out_scp, device, args.sample_rate, args.out_spk_scp, args.spk2utt_file, args.batch_size, args.dtype, args.workers, args.window)
+    main(xtractor, args.wav_scp, args.out_scp, device, args.sample_rate, args.out_spk_scp, args.spk2utt_file, args.batch_size, args.dtype, args.workers or None, args.window, args.gather_always)
     if dist.is_initialized():
         dist.destroy_process_group()
 

@@ -20,7 +20,8 @@ an ``.npz`` with those three arrays (``tests/golden/config5.npz`` holds the ones
 without it a moment estimate (between / within speaker covariance of the training x-vectors) stands in, since PLDA *training*
 proper (``sidekit/factor_analyser.py:830-932``) is out of scope.
 
-``main(argv, model=None, scoring=None)``: the model and the module that scores (``cosine_matrix_device``, ``plda_matrix_device``,
+``main(argv, model=None, scoring=None, keep=None)``: ``keep`` (a dict) receives the gathered x-vectors (``"xv"``, device tensor), the labels and
+rank 0's two score matrices -- for tests that compare two runs; the model and the module that scores (``cosine_matrix_device``, ``plda_matrix_device``,
 ``cosine_histograms``) default to the GPU ones; ``--backend gloo --device cpu`` with injected stand-ins runs this driver's real
 control flow (ragged gather, row shards, ``self_offset``, the counter all-reduce) on CPU ranks (``tests/test_sharding_cpu.py``).
 """
@@ -84,7 +85,7 @@ def load_plda(path):
     return numpy.asarray(mu, dtype=numpy.float64), numpy.asarray(F, dtype=numpy.float64), numpy.asarray(Sigma, dtype=numpy.float64)
 
 
-def main(argv=None, model=None, scoring=None):
+def main(argv=None, model=None, scoring=None, keep=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--utterances", type=int, default=4096)
     ap.add_argument("--batch", type=int, default=256)
@@ -191,10 +192,14 @@ def main(argv=None, model=None, scoring=None):
         t_hist = time.perf_counter() - t0
         counts = counts.cpu().numpy()
         out.update(all_pairs=int(counts.sum()), all_pairs_s=t_hist, all_pairs_eer=float(eer_from_histograms(counts[0], counts[1])))
+    if keep is not None:
+        keep.update(xv=xv, labels=labels, tar=tar)
     if rank == 0:
         for name, rows in (("cosine", cos_rows), ("plda", plda_rows)):
             s = rows.cpu().numpy().astype(float)
             out[f"{name}_eer"] = float(rocch2eer(*rocch(s[tar], s[~tar])))
+            if keep is not None:
+                keep[f"{name}_scores"] = s
         print(json.dumps(out), flush=True)
     if own_group:
         dist.destroy_process_group()

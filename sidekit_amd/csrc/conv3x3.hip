@@ -1184,21 +1184,22 @@ static void fill_geom(ConvGeom& g) {
 // the weight packing at xt_finalize, and in launch_conv), so that a variant can be judged inside the whole forward -- also with two batches in flight,
 // where occupancy is supplied by the other batch's kernels and a shape that loses alone may win.
 static int map_shape(int shape) {
-  static int table[64];
-  static bool init = false;
-  if (!init) {
-    for (int i = 0; i < 64; ++i) table[i] = i;
+  struct Table { int t[64]; };
+  static const Table table = [] {   // function-local static: initialised once, also when two host threads make their first call together
+    Table tb;
+    for (int i = 0; i < 64; ++i) tb.t[i] = i;
     if (const char* e = getenv("SIDEKIT_AMD_SHAPE_MAP")) {
+      fprintf(stderr, "[sidekit_amd] SIDEKIT_AMD_SHAPE_MAP=%s: convolution shapes differ from the product configuration (A/B tuning aid)\n", e);
       int a = 0, b = 0, n = 0;
       while (sscanf(e, "%d=%d%n", &a, &b, &n) == 2) {
-        if (a >= 0 && a < 64 && b >= 0 && b < 64) table[a] = b;
+        if (a >= 0 && a < 64 && b >= 0 && b < 64) tb.t[a] = b;
         e += n;
         if (*e == ';' || *e == ',') ++e; else break;
       }
     }
-    init = true;
-  }
-  return (shape >= 0 && shape < 64) ? table[shape] : shape;
+    return tb;
+  }();
+  return (shape >= 0 && shape < 64) ? table.t[shape] : shape;
 }
 
 int conv_geom(int shape, int dtype, ConvGeom* g) {

@@ -48,6 +48,7 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ fea
       for (int c0 = 0; c0 < 32; c0 += 8) {
         float v[8];
 #pragma unroll
+#ifdef SK_STEM_PACKED   // A/B partner only (round 5): explicit two-element vectors -> v_pk_fma_f32
         for (int c = 0; c < 8; c += 2) {   // two channels per v_pk_fma_f32; w is tap-major [9][32], uniform index -> scalar loads
           f32x2_t s = {shift[c0 + c], shift[c0 + c + 1]};   // w carries the BatchNorm scale (xt_api.hip): bn(conv(x)) = shift + sum w' x
 #pragma unroll
@@ -58,6 +59,14 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ fea
           v[c] = relu_nan(s[0]);
           v[c + 1] = relu_nan(s[1]);
         }
+#else
+        for (int c = 0; c < 8; ++c) {      // one v_fma_f32 per (channel, tap) with the weight as an SGPR operand; w is tap-major [9][32], uniform index -> scalar loads
+          float s = shift[c0 + c];         // w carries the BatchNorm scale (xt_api.hip): bn(conv(x)) = shift + sum w' x
+#pragma unroll
+          for (int q = 0; q < 9; ++q) s = fmaf(w[q * 32 + c0 + c], x[q], s);
+          v[c] = relu_nan(s);
+        }
+#endif
         if constexpr (EB == 2) {
           *reinterpret_cast<uint4*>(lp + c0 * 2) =
               make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));

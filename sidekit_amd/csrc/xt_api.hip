@@ -5,6 +5,7 @@
 #include <stdarg.h>
 #include <string.h>
 
+#include <atomic>
 #include <map>
 #include <string>
 #include <vector>
@@ -148,6 +149,17 @@ struct xt_handle {
   int lanes = lanes_from_env();                    // 1: serial (profiling: per-kernel durations mean something), 2 (default) .. 4: that many parts of a batch side by side
   static constexpr int LANE_MIN = 64;              // utterances per lane below which a batch is not split further
   bool norm_embedding = true;
+  // The stream contract, enforced (round 5).  Workspaces are ordered by STREAM order: an unsplit forward runs on the caller's stream in lane
+  // 0's workspace, a split or pipelined one on streams the handle owns behind an event recorded on the caller's stream.  All of that assumes
+  // consecutive calls arrive on ONE stream; round 4's soak test found the first hole in it (a plain forward racing a pipelined batch in slot
+  // 0).  Now every call that touches a workspace ends by recording `tail` on the stream it was given, and a call that arrives on ANOTHER
+  // stream first makes that stream wait for `tail` and for every lane's completion event -- the library orders itself, whatever stream a
+  // call comes from.  Two host threads inside one handle at once are refused (SK_ESTATE): the host-side bookkeeping (pinned rings, lane
+  // state, reserved shapes) has no lock and is not meant to have one (one handle, one driving thread).
+  std::atomic<bool> busy{false};
+  hipStream_t last_stream = nullptr;
+  bool has_last = false;
+  hipEvent_t tail = nullptr;
   // per-kernel-class HIP-event profile (xt_set_profile)
   uint32_t profile = 0;   // bit (slot + 1) per bracketed slot; 1 = all
   struct ProfRec { int slot; hipEvent_t a, b; };
@@ -162,6 +174,38 @@ struct xt_handle {
 };
 
 namespace sk {
+
+// One host thread at a time per handle; see xt_handle::busy.
+struct EntryGuard {
+  xt_handle* h; bool ok;
+  explicit EntryGuard(xt_handle* h_) : h(h_), ok(h_ && !h_->busy.exchange(true, std::memory_order_acquire)) {}
+  ~EntryGuard() { if (ok) h->busy.store(false, std::memory_order_release); }
+};
+#define SK_ENTER(h)                                                                                                   \
+  SK_CHECK((h) != nullptr, SK_EARG, "null handle");                                                                   \
+  sk::EntryGuard guard_(h);                                                                                           \
+  SK_CHECK(guard_.ok, SK_ESTATE, "concurrent entry: another host thread is inside this handle (a handle is driven by one thread at a time; use one handle per thread)")
+
+// A call that touches a workspace and arrives on another stream than the previous one: order it behind the previous stream's tail and behind
+// whatever the handle's own streams still run (pipelined batches, xt_forward_begin).
+static int enter_stream(xt_handle* h, hipStream_t st) {
+  if (h->has_last && h->last_stream != st) {
+    SK_HIP(hipStreamWaitEvent(st, h->tail, 0));
+    for (int k = 0; k < xt_handle::MAX_LANES; ++k)
+      if (h->lane[k].stream) SK_HIP(hipStreamWaitEvent(st, h->lane[k].join, 0));
+  }
+  return SK_OK;
+}
+// ... and leaves its mark on the stream it ran on (also after an error: whatever was queued before the error is what the next stream must wait for).
+static void leave_stream(xt_handle* h, hipStream_t st) {
+  if (!h->tail && hipEventCreateWithFlags(&h->tail, hipEventDisableTiming) != hipSuccess) { h->tail = nullptr; return; }
+  if (hipEventRecord(h->tail, st) == hipSuccess) { h->last_stream = st; h->has_last = true; }
+}
+struct StreamScope {
+  xt_handle* h; hipStream_t st;
+  StreamScope(xt_handle* h_, hipStream_t st_) : h(h_), st(st_) {}
+  ~StreamScope() { leave_stream(h, st); }
+};
 
 // ---- expected checkpoint keys ------------------------------------------------------------------
 static void add_bn_keys(std::vector<std::pair<std::string, std::vector<int64_t>>>& k, const std::string& p, int64_t c) {
@@ -903,6 +947,7 @@ int xt_destroy(xt_handle* h) {
     if (ln.fork) (void)hipEventDestroy(ln.fork);
     if (ln.join) (void)hipEventDestroy(ln.join);
   }
+  if (h->tail) (void)hipEventDestroy(h->tail);
   for (auto& kv : h->taps) kv.second.buf.release();
   for (auto& r : h->prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
   for (auto e : h->prof_pool) (void)hipEventDestroy(e);
@@ -1038,7 +1083,7 @@ static int reserve_side_lanes(xt_handle* h, int32_t max_batch, int64_t max_sampl
   return SK_OK;
 }
 
-int xt_reserve(xt_handle* h, int32_t max_batch, int64_t max_samples) {
+static int reserve_impl(xt_handle* h, int32_t max_batch, int64_t max_samples) {
   SK_CHECK(h && max_batch > 0 && max_samples > 0, SK_EARG, "xt_reserve: bad arguments");
   SK_HIP(hipSetDevice(h->device));
   SK_TRY(reserve_lane(h, h->lane[0], max_batch, max_samples));
@@ -1047,6 +1092,11 @@ int xt_reserve(xt_handle* h, int32_t max_batch, int64_t max_samples) {
   for (auto& r : h->reserved) covered = covered || (r.first >= max_batch && r.second >= max_samples);
   if (!covered) h->reserved.push_back({max_batch, max_samples});
   return SK_OK;
+}
+
+int xt_reserve(xt_handle* h, int32_t max_batch, int64_t max_samples) {
+  SK_ENTER(h);
+  return reserve_impl(h, max_batch, max_samples);
 }
 
 static int check_run(xt_handle* h, int B, int64_t L_samples) {
@@ -1081,9 +1131,12 @@ static int lane_trunk(xt_handle* h, Lane& ln, const BatchMeta& m, float* d_emb, 
 
 static int forward_wav(xt_handle* h, const void* d_wav, int pcm16, int64_t wav_ld, const int32_t* h_nsamples, int32_t B, int64_t L,
                        float* d_emb, float* d_logits, void* stream) {
+  SK_ENTER(h);
   SK_TRY(check_run(h, B, L));
   SK_CHECK(d_wav && d_emb && wav_ld >= L, SK_EARG, "xt_forward: bad buffers");
   hipStream_t st = (hipStream_t)stream;
+  SK_TRY(enter_stream(h, st));
+  StreamScope scope_(h, st);
   Lane& l0 = h->lane[0];
   int n = (h->debug || h->cfg.arch != XT_ARCH_HALFRESNET34) ? 1 : lane_parts(h->lanes, B, xt_handle::LANE_MIN);
   // fewer parts until every side lane exists (a handle switched after its last reserve) and its workspace covers its part: nothing
@@ -1174,20 +1227,24 @@ static int reserve_slot(xt_handle* h, int slot, int32_t max_batch, int64_t max_s
 
 int xt_reserve_slots(xt_handle* h, int32_t slots, int32_t max_batch, int64_t max_samples) {
   SK_CHECK(h && slots >= 1 && slots <= xt_handle::MAX_LANES && max_batch > 0 && max_samples > 0, SK_EARG, "xt_reserve_slots: 1 .. %d slots", xt_handle::MAX_LANES);
+  SK_ENTER(h);
   SK_HIP(hipSetDevice(h->device));
-  SK_TRY(xt_reserve(h, max_batch, max_samples));          // slot 0 = the handle's full-size workspace; records the shape
+  SK_TRY(reserve_impl(h, max_batch, max_samples));          // slot 0 = the handle's full-size workspace; records the shape
   for (int k = 0; k < slots; ++k) SK_TRY(reserve_slot(h, k, max_batch, max_samples));
   return SK_OK;
 }
 
 int xt_forward_begin(xt_handle* h, int32_t slot, const void* d_wav, int32_t in_dtype, int64_t wav_ld, const int32_t* h_nsamples, int32_t B, int64_t L,
                      float* d_emb, float* d_logits, void* stream) {
+  SK_ENTER(h);
   SK_TRY(check_run(h, B, L));
   SK_CHECK(slot >= 0 && slot < xt_handle::MAX_LANES && h->lane[slot].stream && (slot == 0 || h->lane[slot].covers(B, L)), SK_EWORKSPACE,
            "xt_forward_begin: slot %d has no workspace for %d x %lld samples (xt_reserve_slots)", slot, B, (long long)L);
   SK_CHECK(d_wav && d_emb && wav_ld >= L && (in_dtype == XT_F32 || in_dtype == XT_I16), SK_EARG, "xt_forward_begin: bad buffers");
   SK_CHECK(!h->debug, SK_ESTATE, "xt_forward_begin: debug taps belong to the plain forward");
   Lane& lk = h->lane[slot];
+  SK_TRY(enter_stream(h, (hipStream_t)stream));
+  StreamScope scope_(h, (hipStream_t)stream);
   SK_HIP(hipEventRecord(lk.fork, (hipStream_t)stream));
   SK_HIP(hipStreamWaitEvent(lk.stream, lk.fork, 0));
   static const int cap = getenv("SIDEKIT_AMD_SLOT_PERSIST_CAP") ? atoi(getenv("SIDEKIT_AMD_SLOT_PERSIST_CAP")) : 1;
@@ -1204,6 +1261,7 @@ int xt_forward_begin(xt_handle* h, int32_t slot, const void* d_wav, int32_t in_d
 }
 
 int xt_forward_end(xt_handle* h, int32_t slot, void* stream) {
+  SK_ENTER(h);
   SK_CHECK(h && slot >= 0 && slot < xt_handle::MAX_LANES && h->lane[slot].stream, SK_EARG, "xt_forward_end: slot %d was never reserved", slot);
   SK_HIP(hipStreamWaitEvent((hipStream_t)stream, h->lane[slot].join, 0));
   return SK_OK;
@@ -1211,9 +1269,12 @@ int xt_forward_end(xt_handle* h, int32_t slot, void* stream) {
 
 int xt_forward_features(xt_handle* h, const float* d_feats, const int32_t* h_frames, int32_t B, int32_t T, float* d_emb,
                         float* d_logits, void* stream) {
+  SK_ENTER(h);
   SK_TRY(check_run(h, B, (int64_t)(T > 0 ? T - 1 : 0) * (h ? h->fc.hop : 1)));
   SK_CHECK(d_feats && d_emb && T > 0, SK_EARG, "xt_forward_features: bad buffers");
   hipStream_t st = (hipStream_t)stream;
+  SK_TRY(enter_stream(h, st));
+  StreamScope scope_(h, st);
   BatchMeta m;
   Lane& ln = h->lane[0];
   ln.persist_cap = 0;
@@ -1232,9 +1293,12 @@ int xt_forward_features(xt_handle* h, const float* d_feats, const int32_t* h_fra
 
 int xt_features(xt_handle* h, const float* d_wav, int64_t wav_ld, const int32_t* h_nsamples, int32_t B, int64_t L,
                 float* d_feats_out, void* stream) {
+  SK_ENTER(h);
   SK_TRY(check_run(h, B, L));
   SK_CHECK(d_wav && d_feats_out && wav_ld >= L, SK_EARG, "xt_features: bad buffers");
   hipStream_t st = (hipStream_t)stream;
+  SK_TRY(enter_stream(h, st));
+  StreamScope scope_(h, st);
   BatchMeta m;
   Lane& ln = h->lane[0];
   if (ln.stream) SK_HIP(hipStreamWaitEvent(st, ln.join, 0));   // lane 0's workspace: behind whatever its own stream still runs (forward_wav)
@@ -1256,6 +1320,7 @@ int xt_set_norm_embedding(xt_handle* h, int32_t on) {
 
 int xt_set_lanes(xt_handle* h, int32_t lanes) {
   SK_CHECK(h && lanes >= 1 && lanes <= xt_handle::MAX_LANES, SK_EARG, "xt_set_lanes: 1 (serial) .. %d", xt_handle::MAX_LANES);
+  SK_ENTER(h);
   h->lanes = lanes;
   if (lanes > 1) {   // size the second lane for every shape reserved while the handle was serial
     SK_HIP(hipSetDevice(h->device));

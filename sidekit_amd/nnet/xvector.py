@@ -156,7 +156,14 @@ class Xtractor:
         return (logits, emb) if self.loss == "aam" else emb
 
     # ---- pipelined forwards: two whole batches in flight (xt_forward_begin / xt_forward_end) ---------------------------------------
-    pipeline_depth = min(4, max(1, int(os.environ.get("SIDEKIT_AMD_PIPELINE_DEPTH", "2"))))   # batches in flight; 2 is what pays (3: +0.5 %)
+    @staticmethod
+    def _depth_from_env():
+        try:                                  # a malformed value must not break importing the package
+            return min(4, max(1, int(os.environ.get("SIDEKIT_AMD_PIPELINE_DEPTH", "2"))))
+        except ValueError:
+            return 2
+
+    pipeline_depth = _depth_from_env.__func__()   # batches in flight; 2 is what pays (3: +0.5 %)
 
     def submit(self, x, lengths=None, norm_embedding=True):
         """Queue ``forward(x, is_eval=True)`` WITHOUT waiting for it on the caller's stream and return a ticket for :meth:`collect`.
@@ -184,9 +191,15 @@ class Xtractor:
         logits = torch.empty((B, int(self.speaker_number)), dtype=torch.float32, device=x.device) if self.loss == "aam" else None
         lens = self._lengths(lengths, B, L)
         slot = self._next_slot
-        _lib.check(lib.xt_forward_begin(h, slot, x.data_ptr(), _lib.XT_I16 if x.dtype == torch.int16 else _lib.XT_F32,
-                                        x.stride(0) if B > 1 else L, _ptr(lens), B, L, emb.data_ptr(),
-                                        logits.data_ptr() if logits is not None else None, self._stream(x)))
+        rc = lib.xt_forward_begin(h, slot, x.data_ptr(), _lib.XT_I16 if x.dtype == torch.int16 else _lib.XT_F32,
+                                  x.stride(0) if B > 1 else L, _ptr(lens), B, L, emb.data_ptr(),
+                                  logits.data_ptr() if logits is not None else None, self._stream(x))
+        if rc != _lib.SK_OK:
+            # part of the forward may already be queued on the slot's stream (the library records the slot's completion event on its error
+            # paths too): order the caller's stream behind it BEFORE emb / logits / x go back to the caching allocator with this frame
+            msg = _lib.last_error()
+            lib.xt_forward_end(h, slot, self._stream(x))
+            raise (ValueError if rc == _lib.SK_EARG else RuntimeError)(msg)
         self._next_slot = (slot + 1) % self.pipeline_depth
         ticket = (h, slot, x, logits, emb)        # x is kept alive until the forward that reads it has been waited for
         self._tickets.append(ticket)

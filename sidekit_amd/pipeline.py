@@ -110,6 +110,21 @@ def plan_batches(lengths, batch_size, max_samples=None):
     return batches
 
 
+def host_workers(cap=8):
+    """Decode / staging threads of ONE rank: the cores this process may run on, divided by the ranks that share the host
+    (``LOCAL_WORLD_SIZE`` under torch.distributed.run), at most ``cap`` -- eight ranks with eight threads each on a 64-core share would
+    otherwise oversubscribe it 1:1 before the interpreter, the RCCL proxy and the HIP runtime threads get anything."""
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        cores = os.cpu_count() or 1
+    try:
+        local_world = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))
+    except ValueError:
+        local_world = 1
+    return max(1, min(cap, cores // local_world))
+
+
 class _Staging:
     """One slot of the pinned ring: int16 and float32 host buffers (grown on demand, never shrunk), the device copies,
     and the events that order copy -> compute -> read-back."""
@@ -201,12 +216,12 @@ class StreamingExtractor:
     ``cmd |`` string, an already decoded 1-D array or a callable returning one; ``vec`` is the ``(1, E)`` float32 embedding.  Results arrive batch by
     batch (length-sorted inside a window of ``window * batch_size`` utterances), not in input order."""
 
-    def __init__(self, model, batch_size=256, window=8, workers=8, pending=2, sample_rate=16000, norm_embedding=True, stage_ahead=2,
+    def __init__(self, model, batch_size=256, window=8, workers=None, pending=2, sample_rate=16000, norm_embedding=True, stage_ahead=2,
                  max_samples_per_batch=1 << 26):
         self.model = model
         self.batch_size = max(1, int(batch_size))
         self.window = max(1, int(window))
-        self.workers = max(1, int(workers))
+        self.workers = host_workers() if workers is None else max(1, int(workers))   # None: this rank's share of the host cores
         self.pending = max(1, int(pending))
         self.stage_ahead = max(1, int(stage_ahead))
         self.max_samples_per_batch = max_samples_per_batch   # 2^26 padded samples = 1024 x 4 s: caps staging and activation memory

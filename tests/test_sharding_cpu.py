@@ -79,10 +79,20 @@ class _StubXtractor:
 
 
 def _cli_worker(rank, world, port, wav_scp, out_scp):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LOCAL_WORLD_SIZE=str(world))   # what torch.distributed.run exports
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from sidekit_amd.bin import extract_xvectors
-    extract_xvectors.main(_StubXtractor(), wav_scp, out_scp, "cpu", batch_size=3, workers=2, window=2)
+    seen = []
+
+    class Recording(extract_xvectors.StreamingExtractor):
+        def __init__(self, *a, **k):
+            super().__init__(*a, **k)
+            seen.append(self.workers)
+
+    extract_xvectors.StreamingExtractor = Recording
+    extract_xvectors.main(_StubXtractor(), wav_scp, out_scp, "cpu", batch_size=3, window=2)      # workers: this rank's share of the host
+    with open(f"{out_scp}.workers{rank}", "w") as f:
+        f.write(str(seen[0]))
     dist.destroy_process_group()
 
 
@@ -106,6 +116,19 @@ def test_extract_xvectors_cli_shards_the_wav_scp(tmp_path):
     assert list(got) == [f"utt{i}" for i in range(7)]
     for k, v in expect.items():
         assert got[k].shape == (1, 4) and numpy.allclose(got[k][0], v, rtol=1e-5, atol=1e-3), k
+    # SURVEY 8e, host side: two ranks on one host take half of the cores each for decoding / staging (at most 8), not 8 each
+    share = max(1, min(8, len(os.sched_getaffinity(0)) // 2))
+    for r in range(2):
+        assert int(open(f"{tmp_path / 'xv.scp'}.workers{r}").read()) == share
+    # one process, no process group: the same ark BYTES although its batches come back length-sorted (the reference writes the ark in
+    # wav.scp order, extract_xvectors.py:120,147; a Kaldi consumer reading `ark:` sequentially must not see the launch mode)
+    from sidekit_amd.bin import extract_xvectors
+    (tmp_path / "one").mkdir()
+    extract_xvectors.main(_StubXtractor(), str(tmp_path / "wav.scp"), str(tmp_path / "one" / "xv.scp"), "cpu", batch_size=3, workers=2, window=2)
+    assert open(tmp_path / "one" / "xv.ark", "rb").read() == open(tmp_path / "xv.ark", "rb").read()
+    one = [l.split() for l in open(tmp_path / "one" / "xv.scp")]
+    two = [l.split() for l in open(tmp_path / "xv.scp")]
+    assert [k for k, _ in one] == [k for k, _ in two] and [rx.rpartition(":")[2] for _, rx in one] == [rx.rpartition(":")[2] for _, rx in two]
 
 
 # ---- the sharded extraction + scoring driver itself (bin/shard_extract_score.py) on 2 gloo ranks -------------------------------
