@@ -1,7 +1,6 @@
 #!/bin/bash
 # A/B builds of the library beside the product one: scripts/build_variant.sh <name> [make variables ...]
-#   scripts/build_variant.sh se_scalar SE_SLP=0            -> build_alt/se_scalar/sidekit_amd/csrc/libsidekit_amd.so
-#   scripts/build_variant.sh stem_pk EXTRA=-DSK_STEM_PACKED
+#   scripts/build_variant.sh wino EXTRA=-DSK_SOME_SWITCH   -> build_alt/wino/sidekit_amd/csrc/libsidekit_amd.so
 # The variant is a copy of csrc/ + include/ built in place (build_alt/ is git-ignored and travels to the GPU box); judge it with
 # scripts/ab_pipelined.py on ONE box.
 set -e

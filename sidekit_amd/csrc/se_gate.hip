@@ -1,8 +1,7 @@
 // Squeeze-excite gate of a BasicBlock, computed BEFORE the block's second convolution runs.  Reference: sidekit/nnet/res_net.py:272-281
 // (SELayer); the block tail (gate * out + shortcut, ReLU; res_net.py:316-319) lives in the second convolution's epilogue.
-// This is the one file of the library built WITH SLP vectorisation (csrc/Makefile): its inner loops want packed FMAs (13.7 us per
-// launch against 18.5 us without, sixteen launches per forward), and what SLP forms here is v_pk_fma_f32 with broadcast operands --
-// not the negated / op_sel'ed v_pk_add_f32 / v_pk_mul_f32 family that misbehaves beside another stream's MFMAs.
+// Built like every other file with -fno-slp-vectorize since round 5: rounds 3-4 built this file alone with SLP for its packed FMAs (13.7 vs
+// 18.5 us per launch in a serial forward); inside the pipelined step the difference does not show (profiles/r05_ab_scalar_forms.txt).
 #include "kernels.h"
 
 namespace sk {

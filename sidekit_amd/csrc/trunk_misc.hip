@@ -1,12 +1,13 @@
 // Stem convolution (1 -> 32) of the HalfResNet34 trunk.  Reference: sidekit/nnet/res_net.py:509-515,549.  (The squeeze-excite gate
-// kernel lives in se_gate.hip: it is the one file built WITH SLP vectorisation, see csrc/Makefile.)
+// kernel lives in se_gate.hip.)
 #include "kernels.h"
 
 namespace sk {
 
 // ---- stem: relu(bn(conv3x3(1->32, pad 1))) on the logical (B,1,H=T,W=80) image -----------------
 // One workgroup = TT time rows x 80 freqs; the (TT+2) x 82 input patch goes through LDS, every
-// thread produces one position x 32 channels (288 FMAs as 144 packed-f32 FMAs, weights as SGPR operands) and writes
+// thread produces one position x 32 channels (288 scalar FMAs with the weights as SGPR operands; rounds 3-4 issued them as 144 explicit
+// v_pk_fma_f32 -- no faster inside the pipelined step, and packed f32 is gone from the library since round 5, csrc/Makefile) and writes
 // 64 B (bf16) / 128 B (f32).
 constexpr int STEM_TT = 16;
 constexpr int STEM_W = 80;
@@ -48,25 +49,12 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ fea
       for (int c0 = 0; c0 < 32; c0 += 8) {
         float v[8];
 #pragma unroll
-#ifdef SK_STEM_PACKED   // A/B partner only (round 5): explicit two-element vectors -> v_pk_fma_f32
-        for (int c = 0; c < 8; c += 2) {   // two channels per v_pk_fma_f32; w is tap-major [9][32], uniform index -> scalar loads
-          f32x2_t s = {shift[c0 + c], shift[c0 + c + 1]};   // w carries the BatchNorm scale (xt_api.hip): bn(conv(x)) = shift + sum w' x
-#pragma unroll
-          for (int q = 0; q < 9; ++q) {
-            const f32x2_t wq = {w[q * 32 + c0 + c], w[q * 32 + c0 + c + 1]}, xq = {x[q], x[q]};
-            s = __builtin_elementwise_fma(wq, xq, s);
-          }
-          v[c] = relu_nan(s[0]);
-          v[c + 1] = relu_nan(s[1]);
-        }
-#else
         for (int c = 0; c < 8; ++c) {      // one v_fma_f32 per (channel, tap) with the weight as an SGPR operand; w is tap-major [9][32], uniform index -> scalar loads
           float s = shift[c0 + c];         // w carries the BatchNorm scale (xt_api.hip): bn(conv(x)) = shift + sum w' x
 #pragma unroll
           for (int q = 0; q < 9; ++q) s = fmaf(w[q * 32 + c0 + c], x[q], s);
           v[c] = relu_nan(s);
         }
-#endif
         if constexpr (EB == 2) {
           *reinterpret_cast<uint4*>(lp + c0 * 2) =
               make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));

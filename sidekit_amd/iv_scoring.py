@@ -128,22 +128,47 @@ def cosine_histograms(enroll_vectors, test_vectors, enroll_labels, test_labels, 
     return ht.cpu().numpy().astype(numpy.uint64), hn.cpu().numpy().astype(numpy.uint64)
 
 
+def _speaker_posterior_terms(K):
+    """For ``K`` = speaker-subspace precision gained from ONE observation: the posterior covariances after one and after two observations
+    of a speaker, ``(I + K)^-1`` and ``(I + 2K)^-1``, and the constant of the log-likelihood ratio they leave,
+    ``log|I + K| - 0.5 log|I + 2K|``."""
+    eye = numpy.eye(K.shape[0])
+    one, two = eye + K, eye + 2.0 * K
+    return numpy.linalg.inv(one), numpy.linalg.inv(two), numpy.linalg.slogdet(one)[1] - 0.5 * numpy.linalg.slogdet(two)[1]
+
+
 def plda_parameters(mu, F, Sigma, scaling_factor=1.):
-    """The 256 x 256 float64 algebra of ``fast_PLDA_scoring`` (``iv_scoring.py:428-446``): ``(Phi, Psi, plda_cst)`` such that
-    ``score(e, t) = scaling * (0.5 e'Phi e + 0.5 t'Phi t + plda_cst + e'Psi t)`` for centred vectors."""
-    invSigma = scipy.linalg.inv(Sigma)
-    I_spk = numpy.eye(F.shape[1], dtype='float')
-    K = F.T.dot(invSigma * scaling_factor).dot(F)
-    K1 = scipy.linalg.inv(K + I_spk)
-    K2 = scipy.linalg.inv(2 * K + I_spk)
-    plda_cst = numpy.linalg.slogdet(K2)[1] / 2.0 - numpy.linalg.slogdet(K1)[1]
-    Sigma_ac = numpy.dot(F, F.T)
-    Sigma_tot = Sigma_ac + Sigma
-    Sigma_tot_inv = scipy.linalg.inv(Sigma_tot)
-    Tmp = numpy.linalg.inv(Sigma_tot - Sigma_ac.dot(Sigma_tot_inv).dot(Sigma_ac))
-    Phi = Sigma_tot_inv - Tmp
-    Psi = Sigma_tot_inv.dot(Sigma_ac).dot(Tmp)
+    """The D x D float64 algebra of two-covariance PLDA scoring, kept on the host as the reference keeps it (``iv_scoring.py:428-446``):
+    ``(Phi, Psi, plda_cst)`` such that ``score(e, t) = scaling * (0.5 e'Phi e + 0.5 t'Phi t + plda_cst + e'Psi t)`` for centred vectors.
+
+    A same-speaker pair ``(e, t)`` is jointly Gaussian with covariance ``[[T, A], [A, T]]`` (``A = F F'`` across speakers, ``T = A + Sigma``
+    total), a different-speaker pair with ``[[T, 0], [0, T]]``; the log-likelihood ratio's quadratic form is the difference of the two
+    precisions, whose blocks follow from the Schur complement ``S = T - A T^-1 A``: diagonal ``T^-1 - S^-1``, off-diagonal ``T^-1 A S^-1``."""
+    F = numpy.asarray(F, dtype=numpy.float64)
+    within = numpy.asarray(Sigma, dtype=numpy.float64)
+    across = F @ F.T
+    total = across + within
+    total_inv = numpy.linalg.inv(total)
+    schur_inv = numpy.linalg.inv(total - across @ total_inv @ across)
+    Phi = total_inv - schur_inv
+    Psi = total_inv @ across @ schur_inv
+    _, _, plda_cst = _speaker_posterior_terms(scaling_factor * (F.T @ numpy.linalg.solve(within, F)))
     return Phi, Psi, plda_cst
+
+
+def full_plda_parameters(F, G, Sigma, scaling_factor=1.):
+    """Host algebra of PLDA with a channel sub-space (``iv_scoring.py:299-330``): ``(B, Phi, Psi, constant)`` with which the reference's
+    per-model loop becomes the two-covariance kernel's form on projected vectors ``e' = B e``, ``t' = B t`` (module docstring).
+
+    Precision of an observation once the channel factor is integrated out (Woodbury on ``Sigma + G G'``), then everything lives in the
+    speaker sub-space: ``B`` projects a centred vector there and ``B F`` is what one observation adds to the speaker's posterior precision."""
+    F, G = numpy.asarray(F, dtype=numpy.float64), numpy.asarray(G, dtype=numpy.float64)
+    prec = scaling_factor * numpy.linalg.inv(numpy.asarray(Sigma, dtype=numpy.float64))
+    PG = prec @ G
+    prec_marg = prec - PG @ numpy.linalg.inv(numpy.eye(G.shape[1]) + G.T @ PG) @ PG.T
+    B = F.T @ prec_marg
+    K1, K2, constant = _speaker_posterior_terms(B @ F)
+    return B, K2 - K1, 0.5 * (K2 + K2.T), constant
 
 
 def _open_set(scoremat, p_known):
@@ -197,20 +222,11 @@ def full_PLDA_scoring(enroll, test, ndx, mu, F, G, Sigma, p_known=0.0, scaling_f
     clean_ndx = _check_missing_model(enroll_copy, test_copy, ndx) if check_missing else ndx
     enroll_copy.center_stat1(mu)
     test_copy.center_stat1(mu)
-    invSigma = scipy.linalg.inv(Sigma)
-    I_iv = numpy.eye(mu.shape[0], dtype='float')
-    I_ch = numpy.eye(G.shape[1], dtype='float')
-    I_spk = numpy.eye(F.shape[1], dtype='float')
-    A = numpy.linalg.inv(G.T.dot(invSigma * scaling_factor).dot(G) + I_ch)
-    B = F.T.dot(invSigma * scaling_factor).dot(I_iv - G.dot(A).dot(G.T).dot(invSigma * scaling_factor))
-    K = B.dot(F)
-    K1 = scipy.linalg.inv(K + I_spk)
-    K2 = scipy.linalg.inv(2 * K + I_spk)
-    constant = numpy.linalg.slogdet(K2)[1] / 2.0 - numpy.linalg.slogdet(K1)[1]
-    enroll_tmp = enroll_copy.stat1.dot(B.T)   # (Ne, rank): speaker-subspace projections
-    test_tmp = test_copy.stat1.dot(B.T)
+    B, Phi, Psi, constant = full_plda_parameters(F, G, Sigma, scaling_factor)
+    enroll_tmp = enroll_copy.stat1 @ B.T      # (Ne, rank): speaker-subspace projections
+    test_tmp = test_copy.stat1 @ B.T
     score = Scores()
-    score.scoremat = plda_matrix(enroll_tmp, test_tmp, K2 - K1, 0.5 * (K2 + K2.T), constant, scaling_factor, device)
+    score.scoremat = plda_matrix(enroll_tmp, test_tmp, Phi, Psi, constant, scaling_factor, device)
     score.modelset = clean_ndx.modelset
     score.segset = clean_ndx.segset
     score.scoremask = clean_ndx.trialmask

@@ -135,35 +135,42 @@ class StatServer:
         return numpy.dot(c.transpose(), c) / self.stat1.shape[0]
 
     def norm_stat1(self):
-        """Divide every first-order statistic by its Euclidean norm (clipped at 1e-8)."""
-        vect_norm = numpy.clip(numpy.linalg.norm(self.stat1, axis=1), 1e-08, numpy.inf)
-        self.stat1 = (self.stat1.transpose() / vect_norm).transpose()
+        """Every session's first-order statistic scaled to unit Euclidean length; a (near-)zero vector is divided by 1e-8 instead
+        (``statserver.py:797-800``)."""
+        x = self.stat1
+        length = numpy.sqrt((x * x).sum(axis=1))
+        self.stat1 = x / numpy.maximum(length, 1e-08)[:, numpy.newaxis]
 
     def rotate_stat1(self, R):
-        self.stat1 = numpy.dot(self.stat1, R)
+        self.stat1 = self.stat1 @ R
+
+    def _blocks(self):
+        """``stat1`` seen as (sessions, distributions, features per distribution): x-vectors are the one-distribution case."""
+        n, n_distrib = self.stat0.shape
+        return self.stat1.reshape(n, n_distrib, self.stat1.shape[1] // n_distrib)
 
     def center_stat1(self, mu):
-        dim = self.stat1.shape[1] // self.stat0.shape[1]
-        index_map = numpy.repeat(numpy.arange(self.stat0.shape[1]), dim)
-        self.stat1 = self.stat1 - (self.stat0[:, index_map] * mu.astype(STAT_TYPE))
+        """Subtract the occupation-weighted mean: block c of a session loses ``stat0[session, c] * mu[block c]`` (``statserver.py:810-817``)."""
+        blocks = self._blocks()
+        mean = numpy.asarray(mu, dtype=STAT_TYPE).reshape(blocks.shape[1], blocks.shape[2])
+        self.stat1 = (blocks - self.stat0[:, :, numpy.newaxis] * mean).reshape(self.stat1.shape)
 
     def whiten_stat1(self, mu, sigma, isSqrInvSigma=False):
-        """Centre on ``mu`` then whiten with a diagonal (1-D) or full (2-D) covariance."""
-        if sigma.ndim == 1:
-            self.center_stat1(mu)
-            self.stat1 = self.stat1 / numpy.sqrt(sigma.astype(STAT_TYPE))
-        elif sigma.ndim == 2:
-            sqr_inv_sigma = sigma
-            if not isSqrInvSigma:
-                eigen_values, eigen_vectors = scipy.linalg.eigh(sigma)
-                ind = eigen_values.real.argsort()[::-1]
-                eigen_values = eigen_values.real[ind]
-                eigen_vectors = eigen_vectors.real[:, ind]
-                sqr_inv_sigma = numpy.dot(eigen_vectors, numpy.diag(1 / numpy.sqrt(eigen_values.real)))
-            self.center_stat1(mu)
-            self.rotate_stat1(sqr_inv_sigma)
-        else:
+        """Centre on ``mu``, then whiten: by the square roots of a diagonal covariance (1-D ``sigma``), or by ``V diag(lambda^-1/2)`` of a
+        full one (2-D; eigenvalues in descending order, ``statserver.py:852-896``) -- or by ``sigma`` itself when the caller already
+        holds that matrix (``isSqrInvSigma``)."""
+        if sigma.ndim not in (1, 2):
             raise Exception('Wrong dimension of Sigma, must be 1 or 2')
+        self.center_stat1(mu)
+        if sigma.ndim == 1:
+            self.stat1 = self.stat1 / numpy.sqrt(sigma.astype(STAT_TYPE))
+            return
+        transform = sigma
+        if not isSqrInvSigma:
+            lam, vec = scipy.linalg.eigh(sigma)                     # ascending
+            lam, vec = lam.real[::-1], vec.real[:, ::-1]            # largest first
+            transform = vec * (1 / numpy.sqrt(lam))[numpy.newaxis, :]
+        self.rotate_stat1(transform)
 
     def mean_stat_per_model(self):
         """Average the statistics of the sessions sharing a model id -> one session per (sorted) model."""

@@ -1,0 +1,116 @@
+"""bf16 judged by EER, end to end, on ONE discriminative corpus (north_star: "EER within +-0.05 % absolute").
+
+The reference judges a model by the EER of its real embeddings on a trial list (``test_metrics``, sidekit/nnet/xvector.py:212-271) and
+runs its trunk in reduced precision under autocast (``:1890``).  No trained checkpoint or dataset exists offline, so the corpus is the
+synthetic one of ``bin/shard_extract_score`` (250 sinusoid "speakers", per-utterance phases / amplitude jitter / white noise) on which
+the randomly initialised extractor separates speakers: the SAME waveforms go through the fp32 trunk and through the bf16 trunk
+(the headline dtype), the SAME trial set is scored (cosine, two-covariance PLDA estimated from each run's own x-vectors, all pairs of
+the corpus through the histogram kernel), and the EERs are compared.  Until round 4 this rested on bf16 deltas transplanted onto
+synthetic 256-d points (tests/test_gpu_fullsize.py::test_bf16_deviation_does_not_move_the_eer).
+
+The fp32 leg is itself anchored: its first 64 x-vectors against ``oracle.xvector.halfresnet34_forward`` on the regenerated waveforms
+(<= 1e-4 relative, the north_star's fp32 tolerance).
+
+Calibration (scripts/eer_dtype_sweep.py, profiles/r05_eer_dtype_sweep.txt): noise 0.0005 puts the cosine EER at 4.0 % (SURVEY 8d
+config 5's 1-5 % band; the corpus' floor -- amplitude jitter and phases, not noise), the second operating point is at a higher noise level."""
+import json
+import os
+
+import numpy
+import pytest
+import torch
+
+from oracle import xvector as oxv
+from sidekit_amd.bin import shard_extract_score
+from sidekit_amd.nnet import Xtractor
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PLDA5 = os.path.join(ROOT, "tests", "golden", "config5.npz")
+N_UTT, N_TRIALS, BATCH = 8192, 2000, 256        # 4 M trials, 16 000 of them targets: one target is 0.006 % of EER
+
+
+@pytest.fixture(scope="module")
+def model(gpu):
+    return Xtractor(7205, model_archi="halfresnet34", loss="aam", seed=1234).to(gpu).eval()
+
+
+def _run(model, dtype, noise, plda=None):
+    keep = {}
+    model.compute_dtype = dtype
+    argv = ["--utterances", str(N_UTT), "--batch", str(BATCH), "--seconds", "4", "--trials", str(N_TRIALS), "--noise", str(noise),
+            "--dtype", dtype, "--all-pairs"] + (["--plda", plda] if plda else [])
+    out = shard_extract_score.main(argv, model=model, keep=keep)
+    return out, keep
+
+
+def _record(name, rows):
+    scratch = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(scratch):            # profiles/r05_eer_fp32_vs_bf16.json is a copy of this file
+        with open(os.path.join(scratch, name), "a") as f:
+            for r in rows:
+                f.write(json.dumps(r) + "\n")
+
+
+@pytest.mark.parametrize("noise,band", [(0.0005, (0.01, 0.05)), (0.008, (0.10, 0.25))])
+def test_bf16_and_fp32_give_the_same_eer_on_one_corpus(model, noise, band, capsys):
+    """8192 utterances x 4 s, 2000 x 2000 trials + all 67 M pairs, fp32 vs bf16 trunk: |dEER| <= 0.05 % absolute for cosine, for PLDA with
+    parameters estimated from the run's own x-vectors, and for the all-pairs histograms.  The reference-trained config-5 PLDA parameters
+    (tests/golden/config5.npz) are scored too: they model OTHER embeddings (EER 20-40 % here, a flat DET curve), so their EER is reported
+    and bounded by 0.5 % absolute only."""
+    try:
+        f32, k32 = _run(model, "fp32", noise)
+        b16, k16 = _run(model, "bf16", noise)
+        f32p, _ = _run(model, "fp32", noise, PLDA5)
+        b16p, _ = _run(model, "bf16", noise, PLDA5)
+    finally:
+        model.compute_dtype = None
+    capsys.readouterr()
+    keys = ("cosine_eer", "plda_eer", "all_pairs_eer")
+    delta = {k: b16[k] - f32[k] for k in keys}
+    row = {"noise": noise, "utterances": N_UTT, "trials": N_TRIALS * N_TRIALS, "all_pairs": f32["all_pairs"],
+           "fp32": {k: f32[k] for k in keys}, "bf16": {k: b16[k] for k in keys}, "delta_abs": delta,
+           "plda_config5": {"fp32": f32p["plda_eer"], "bf16": b16p["plda_eer"], "delta_abs": b16p["plda_eer"] - f32p["plda_eer"]},
+           "xvector_cosine_bf16_vs_fp32_min": float(torch.nn.functional.cosine_similarity(k16["xv"], k32["xv"]).min()),
+           "x_vectors_per_s": {"fp32": f32["x_vectors_per_s"], "bf16": b16["x_vectors_per_s"]}}
+    _record("eer_fp32_vs_bf16.json", [row])
+    print(json.dumps(row))
+    assert f32["utterances"] == b16["utterances"] == N_UTT and f32["all_pairs"] == N_UTT * (N_UTT - 1)
+    assert band[0] < f32["cosine_eer"] < band[1], f"the corpus left its calibrated band: cosine EER {f32['cosine_eer']:.4f}"
+    for k in keys:
+        assert abs(delta[k]) <= 5e-4, (k, f32[k], b16[k])
+    assert f32p["cosine_eer"] == f32["cosine_eer"] and b16p["cosine_eer"] == b16["cosine_eer"]        # same extraction, bit for bit
+    assert abs(b16p["plda_eer"] - f32p["plda_eer"]) <= 5e-3, (f32p["plda_eer"], b16p["plda_eer"])
+    # the two runs saw the same waveforms: every bf16 x-vector is its fp32 x-vector up to the trunk's rounding
+    assert row["xvector_cosine_bf16_vs_fp32_min"] > 0.999
+
+
+def test_the_fp32_leg_is_the_oracle(model):
+    """The first 64 utterances of the corpus (regenerated from the driver's own seed recipe) through the oracle's CPU restatement of the
+    reference forward: the fp32 run of the EER comparison is within the north_star's 1e-4 of it."""
+    noise, L = 0.0005, 64000
+    keep = {}
+    model.compute_dtype = "fp32"
+    try:
+        shard_extract_score.main(["--utterances", "1024", "--batch", "256", "--seconds", "4", "--trials", "250", "--noise", str(noise), "--dtype", "fp32"],
+                                 model=model, keep=keep)
+    finally:
+        model.compute_dtype = None
+    labels = numpy.random.RandomState(1).randint(0, 250, 1024).astype(numpy.int32)
+    assert numpy.array_equal(labels, keep["labels"])
+    freqs, amps = shard_extract_score.speaker_table(250)
+    dev = keep["xv"].device
+    g = torch.Generator(device=dev).manual_seed(1000)                        # the batch that starts at utterance 0
+    wav = shard_extract_score.synth_batch(labels[:256], freqs, amps, L, noise, g, dev)[:64].cpu()
+    with torch.no_grad():
+        ref = torch.cat([oxv.halfresnet34_forward(wav[i:i + 16], model.state_dict())[1] for i in range(0, 64, 16)])
+    got = keep["xv"][:64].cpu()
+    rel = ((got - ref).norm(dim=1) / ref.norm(dim=1)).max().item()
+    assert rel < 1e-4, rel
+    # and the corpus is discriminative for this extractor: same-speaker pairs score higher than different-speaker pairs
+    s = (got @ got.t()).numpy()
+    same = labels[:64, None] == labels[None, :64]
+    off = ~numpy.eye(64, dtype=bool)
+    if (same & off).any():
+        assert s[same & off].mean() > s[~same].mean()

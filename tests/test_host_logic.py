@@ -249,3 +249,28 @@ def test_compute_metrics_three_lines(tmp_path, capsys):
     assert abs(float(out[0].split()[1]) / 100 - cm.eer_from_files(str(tmp_path / "scores"), str(tmp_path / "key"))) < 5e-5
     cmin_s, cact_s = (float(x) for x in out[1].split()[2:4])
     assert 0.0 <= cmin_s <= cact_s and 0.0 <= float(out[2].split()[1]) <= 1.0
+
+
+def test_plda_host_algebra_against_the_oracle(golden_dir):
+    """``iv_scoring.plda_parameters`` / ``full_plda_parameters`` (the D x D float64 algebra that stays on the host, ``sidekit/iv_scoring.py:299-330,
+    428-446``) are written from the model (Schur complement of the pair covariance; Woodbury for the channel term), the oracle follows the
+    reference's statements: the same matrices to float64 round-off on the reference-trained config-5 parameters, and the same scores when
+    the kernel's form ``s (0.5 e'Phi e + 0.5 t'Phi t + c + e'Psi t)`` is evaluated in numpy."""
+    from oracle import scoring as osc
+    from sidekit_amd import iv_scoring
+    z = numpy.load(os.path.join(golden_dir, "config5.npz"))
+    mu, F, Sigma = (numpy.asarray(z[k], dtype=numpy.float64) for k in ("mu", "F", "Sigma"))
+    for scaling in (1.0, 0.7):
+        Phi, Psi, cst = iv_scoring.plda_parameters(mu, F, Sigma, scaling)
+        rPhi, rPsi, rcst = osc.fast_plda_matrices(F, Sigma, scaling)
+        assert numpy.abs(Phi - rPhi).max() <= 1e-10 * numpy.abs(rPhi).max()
+        assert numpy.abs(Psi - rPsi).max() <= 1e-10 * numpy.abs(rPsi).max()
+        assert abs(cst - rcst) <= 1e-10 * abs(rcst)
+    rs = numpy.random.RandomState(3)
+    G = 0.3 * rs.randn(F.shape[0], 24)
+    e, t = rs.randn(17, F.shape[0]) + mu, rs.randn(23, F.shape[0]) + mu
+    B, Phi, Psi, c = iv_scoring.full_plda_parameters(F, G, Sigma, 0.9)
+    ep, tp = (e - mu) @ B.T, (t - mu) @ B.T
+    got = 0.9 * (0.5 * numpy.einsum("ij,jk,ik->i", ep, Phi, ep)[:, None] + 0.5 * numpy.einsum("ij,jk,ik->i", tp, Phi, tp)[None, :] + c + ep @ Psi @ tp.T)
+    want = osc.full_plda_scores(e, t, mu, F, G, Sigma, scaling_factor=0.9)
+    assert numpy.abs(got - want).max() <= 1e-9 * numpy.abs(want).max()

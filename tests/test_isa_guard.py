@@ -6,12 +6,12 @@ bf16 MFMAs on the same SIMDs.  The library is therefore built without them.  Thi
 `libsidekit_amd.so` (llvm-objdump cross-disassembles gfx950 on a CPU-only host) and fails if the family comes back: a compiler bump,
 a dropped flag, an explicit float2 expression, a new file.
 
-Rules (kernel names are the demangled prefixes of the device symbols):
-  1. no `v_pk_add_f32` / `v_pk_mul_f32` with ANY operand modifier (`op_sel`, `op_sel_hi`, `neg_lo`, `neg_hi`), anywhere;
-  2. no packed-f32 arithmetic at all outside the two kernels that carry explicit / SLP-formed packed FMAs and are covered by the
-     beside-MFMA regression test on the GPU (`tests/test_gpu_fullsize.py::test_small_kernels_are_stable_beside_another_streams_bf16_trunk`):
-     `stem_kernel` and `se_pre_kernel`;
-  3. inside those two: only `v_pk_fma_f32` without negation and plain (modifier-free) `v_pk_add_f32`.
+The rule since round 5: NO packed-f32 arithmetic (`v_pk_add_f32` / `v_pk_mul_f32` / `v_pk_fma_f32`) anywhere in the library.  Rounds
+3-4 kept two exceptions -- `stem_kernel`'s explicit two-element FMAs and `se_pre_kernel`, the one file built with SLP -- on the evidence
+"never seen to misbehave" and a speed argument measured in a serial forward (13.7 vs 18.5 us per SE gate).  Judged inside the
+pipelined product schedule on one box (scripts/ab_pipelined.py, profiles/r05_ab_scalar_forms.txt) the scalar forms cost nothing:
+5.533 / 5.530 / 5.525 ms per batch of 256 (shipped scalar stem + SLP gate / both scalar / both packed), batch 1 0.671 ms for all
+three -- so the exposure went and the exception with it.
 """
 import glob
 import os
@@ -25,7 +25,6 @@ import pytest
 from sidekit_amd import _lib
 
 OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
-ALLOWED_KERNELS = ("stem_kernel", "se_pre_kernel")
 PK_F32 = re.compile(r"\b(v_pk_(?:add|mul|fma)_f32)\b(.*)")
 
 
@@ -61,23 +60,14 @@ def test_no_modified_packed_f32_in_the_shipped_library():
             found += _scan(dis)
             n_mfma += len(re.findall(r"\bv_mfma_", dis))
     assert n_mfma > 10000, f"disassembly looks empty ({n_mfma} MFMA instructions): the guard would be vacuous"
-    bad = []
-    for kernel, op, operands in found:
-        modified = any(t in operands for t in ("op_sel", "neg_lo", "neg_hi"))
-        negated = "neg_lo" in operands or "neg_hi" in operands
-        allowed_kernel = any(name in kernel for name in ALLOWED_KERNELS)
-        if op in ("v_pk_add_f32", "v_pk_mul_f32") and modified:
-            bad.append((kernel, op, operands, "rule 1: modified packed add / mul"))
-        elif not allowed_kernel:
-            bad.append((kernel, op, operands, "rule 2: packed f32 outside stem_kernel / se_pre_kernel"))
-        elif op == "v_pk_mul_f32" or negated:
-            bad.append((kernel, op, operands, "rule 3: only un-negated v_pk_fma_f32 and plain v_pk_add_f32 are allowed here"))
-    assert not bad, "packed-f32 instructions of the hazardous family are back in libsidekit_amd.so:\n" + "\n".join(
+    bad = [(kernel, op, operands, "modified packed add / mul: the round-3 hazard family" if (op != "v_pk_fma_f32" and any(t in operands for t in ("op_sel", "neg_lo", "neg_hi")))
+            else "packed f32 arithmetic") for kernel, op, operands in found]
+    assert not bad, "packed-f32 instructions are back in libsidekit_amd.so (build every file with -fno-slp-vectorize, no explicit float2 arithmetic):\n" + "\n".join(
         f"  {k}: {o} {a}   [{why}]" for k, o, a, why in bad[:20]) + (f"\n  ... {len(bad)} in all" if len(bad) > 20 else "")
 
 
 def test_scanner_sees_the_hazardous_forms():
-    """The parser itself: the round-3 sequence (profiles/r04_hazard_isa_diff.txt) must be flagged, the allowed forms must not."""
+    """The parser itself: the round-3 sequence (profiles/r04_hazard_isa_diff.txt) and the forms rounds 3-4 tolerated are all seen."""
     sample = """
 0000000000001900 <_ZN2sk21stft_power_fft_kernelENS_7FftArgsE>:
 	v_pk_add_f32 v[14:15], v[14:15], v[16:17] neg_lo:[0,1] neg_hi:[0,1]   // 000000001A2C: D3B2400E 1802210E
