@@ -184,7 +184,15 @@ def main(argv=None, model=None, scoring=None, keep=None):
         a, b = shard_range(N, rank, world)
         lab_d = torch.as_tensor(labels, device=dev)
         t0 = time.perf_counter()
-        ht, hn = scoring.cosine_histograms(xv[a:b], xv, lab_d[a:b], lab_d, self_offset=a, device=dev)
+        # histogram range from a strided sample of the gathered x-vectors (the same on every rank, no collective): 8192 bins over
+        # [-1, 1) are 2.4e-4 wide, and an extractor whose x-vectors share a common direction (every score in [0.98, 1]) would land in a few
+        # dozen of them -- the binned EER then carries the bin width, not the scores.  The bins go where the scores are (widened by a quarter
+        # of the sampled range; whatever falls outside is counted in the end bins by the kernel).
+        sample = xv[:: max(1, N // 2048)][:2048]
+        smin = float(scoring.cosine_matrix_device(sample, sample, dev).min())
+        lo = max(-1.0, smin - 0.25 * (1.0 - smin))
+        ht, hn = scoring.cosine_histograms(xv[a:b], xv, lab_d[a:b], lab_d, self_offset=a, lo=lo, hi=1.0 + 1e-6, device=dev)
+        out["all_pairs_hist_range"] = [lo, 1.0]
         sync()
         counts = torch.as_tensor(numpy.stack([ht, hn]).astype(numpy.int64), device=dev)
         if dist.is_initialized():

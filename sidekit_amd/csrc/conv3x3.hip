@@ -22,6 +22,7 @@
 //    CU at 168 registers for layers 2-3, small tiles for the stride-2 shapes (DESIGN.md section 4 has the measurements
 //    behind each choice).
 #include "kernels.h"
+#include "se_gate_inl.h"
 
 namespace sk {
 
@@ -227,11 +228,22 @@ struct ConvCfg {
 enum { FORM_PLAIN = 0, FORM_STATS = 1, FORM_RESID = 2, FORM_RESID_SC = 3 };   // 3: residual form, 1x1 shortcut conv computed in place
 template <int F> struct FormTag { static constexpr int value = F; };
 
-template <class C, bool SC, int FORM>
-__global__ __launch_bounds__(C::WM * C::WN * 64, SC ? 1 : C::OCC)
+// GATEPRO (round 5, residual forms only): the block's SE gate is computed in THIS kernel's prologue by every workgroup (se_gate_inl.h) instead
+// of by a launch of its own between conv1 and conv2 -- a separate instantiation selected for small grids (batch <= 8), so the batch-256
+// kernels keep their register and LDS budgets.  The gate arithmetic needs 43 KB of LDS scratch: beside the halo tile where both fit a CU's
+// 160 KB (every bf16 shape: the prologue then runs while the tile's LDS-DMA is in flight), else in the tile buffer before it is staged.
+template <class C, bool SC, int FORM, bool GATEPRO = false>
+__global__ __launch_bounds__(C::WM * C::WN * 64, (SC || GATEPRO) ? 1 : C::OCC)   // GATEPRO: one workgroup per CU anyway (97 KB of LDS) -- the whole register file, no spills
 void conv3x3_kernel(ConvArgs a) {
   using T = typename C::T;
   constexpr int NWAVES = C::WM * C::WN, NTHREADS = NWAVES * 64;
+  static_assert(!GATEPRO || ((FORM == FORM_RESID || FORM == FORM_RESID_SC) && !C::DIRECT && !SC && NTHREADS == 256), "gate prologue: residual forms on 256 threads");
+  constexpr int GATE_SCRATCH = SE_GATE_SCRATCH_FLOATS * 4;
+  constexpr bool GATE_BESIDE = GATEPRO && C::LDS + GATE_SCRATCH + C::COUT * 4 + 1024 <= 160 * 1024;
+  static_assert(!GATEPRO || GATE_BESIDE || C::LDS >= GATE_SCRATCH, "gate prologue: the scratch must fit the tile buffer");
+  __shared__ __attribute__((aligned(16))) float gate_scratch[GATE_BESIDE ? SE_GATE_SCRATCH_FLOATS : 4];
+  __shared__ __attribute__((aligned(16))) float gate_s[GATEPRO ? C::COUT : 4];
+  int gate_for = -1;   // utterance whose gate gate_s holds (a persistent workgroup may walk tiles of several)
   // NT < COUT (layer 4: 128 of 256 output channels per workgroup): the NY workgroups of a work item read the SAME halo tile, so
   // they sit NY x 8 apart in a 1-D grid -- block ids b and b + 8 share an XCD (round-robin dispatch) and start together, which
   // makes the second read of the tile an L2 hit instead of a second trip to HBM (grid.y = 2 moved 1.58 x the algorithmic bytes)
@@ -418,6 +430,13 @@ void conv3x3_kernel(ConvArgs a) {
         if constexpr (SC) acc_sc[i][j][q] = 0.f;
       }
 
+  if constexpr (GATEPRO && !GATE_BESIDE) {   // no room beside the tile (f32 layer 4): the gate first, in the tile buffer the previous item has left
+    if (gate_for != b) {
+      float* gs = reinterpret_cast<float*>(smem);
+      se_gate_block<std::conditional_t<C::EB == 2, uint16_t, float>, C::COUT, NTHREADS>(a.se, b, tid, gs, gs + 8192, gs + 8192 + 2304, gs + 8192 + 2304 + 256, gate_s);
+      gate_for = b;
+    }
+  }
   for (int ch = 0; ch < C::NCH; ++ch) {
     if constexpr (!RESIDENT) load_weights(ch);
     __builtin_amdgcn_sched_barrier(0);  // keep the loads up here: the scheduler otherwise sinks them next to their use
@@ -457,6 +476,13 @@ void conv3x3_kernel(ConvArgs a) {
       }
     }
     stamp(1);
+    if constexpr (GATE_BESIDE) {   // the tile is on its way into LDS: this utterance's SE gate meanwhile (ends with a barrier)
+      if (ch == 0 && gate_for != b) {
+        float* gs = gate_scratch;
+        se_gate_block<std::conditional_t<C::EB == 2, uint16_t, float>, C::COUT, NTHREADS>(a.se, b, tid, gs, gs + 8192, gs + 8192 + 2304, gs + 8192 + 2304 + 256, gate_s);
+        gate_for = b;
+      }
+    }
     __syncthreads();
     stamp(2);
     __builtin_amdgcn_s_setprio(0);
@@ -749,7 +775,7 @@ void conv3x3_kernel(ConvArgs a) {
       for (int q = 0; q < NSUM; ++q) ssum[q] = 0.f;
     }
     auto ld4 = [&](const float* p, int g) { return *reinterpret_cast<const f32x4*>(p + nbase + coff(g)); };
-    const float* gate_b = (RESID || RSC) ? gate + (size_t)b * C::COUT : scale;
+    const float* gate_b = GATEPRO ? gate_s : ((RESID || RSC) ? gate + (size_t)b * C::COUT : scale);
     // one (M-tile i, channel group g) cell: 4 values -> BN, gate or ReLU, rounding, plane sums, 8/16 B into the out tile
     auto cell = [&](int i, int g, const f32x4& sc, const f32x4& sh, const f32x4& gt, auto full_tag) {
       const int m = pos_of(i, g);
@@ -1045,7 +1071,7 @@ static int cu_count() {
   return n;
 }
 
-template <class C>
+template <class C, bool PRODUCT = false>
 static int launch_cfg(const ConvArgs& a, hipStream_t st) {
   const int tiles = cdiv(a.Hout, C::TH), nwork = a.B * tiles;
   // weight-resident shapes: just the workgroups the chip holds at once (LDS and the compiled-for occupancy), persistent
@@ -1082,9 +1108,19 @@ static int launch_cfg(const ConvArgs& a, hipStream_t st) {
       SK_HIP(hipGetLastError());
       return SK_OK;
     }
+    constexpr bool CAN_GATEPRO = PRODUCT && C::S == 1 && C::CIN == C::COUT && NWV == 4 && !C::DIRECT;   // the trunk's conv2 shapes (not their A/B alternatives: compile time)
+    SK_CHECK(!a.gate_pro || (CAN_GATEPRO && a.gate && a.se.C == C::COUT && a.se.se_part && a.se.w2t && a.se.w2t_bf16 == (C::EB == 2)), SK_EARG,
+             "gate prologue: a residual-form convolution of the trunk with the block's SE arguments");
     if constexpr (C::S == 1 && C::CIN == C::COUT) {
       if (a.gate && a.sc_in) {  // first block of a layer: the 1x1 shortcut conv of the block input evaluated in this epilogue
         SK_CHECK(a.sc_wpack && a.sc_scale && a.sc_shift && !a.shortcut, SK_EARG, "in-place shortcut form: bad arguments");
+        if constexpr (CAN_GATEPRO) {
+          if (a.gate_pro) {
+            hipLaunchKernelGGL((conv3x3_kernel<C, false, FORM_RESID_SC, true>), grid, block, 0, st, a);
+            SK_HIP(hipGetLastError());
+            return SK_OK;
+          }
+        }
         hipLaunchKernelGGL((conv3x3_kernel<C, false, FORM_RESID_SC>), grid, block, 0, st, a);
         SK_HIP(hipGetLastError());
         return SK_OK;
@@ -1092,6 +1128,13 @@ static int launch_cfg(const ConvArgs& a, hipStream_t st) {
     }
     if constexpr (C::S == 1) {
       if (a.gate) {
+        if constexpr (CAN_GATEPRO) {
+          if (a.gate_pro) {
+            hipLaunchKernelGGL((conv3x3_kernel<C, false, FORM_RESID, true>), grid, block, 0, st, a);
+            SK_HIP(hipGetLastError());
+            return SK_OK;
+          }
+        }
         hipLaunchKernelGGL((conv3x3_kernel<C, false, FORM_RESID>), grid, block, 0, st, a);
         SK_HIP(hipGetLastError());
         return SK_OK;
@@ -1222,7 +1265,7 @@ int launch_conv(int shape, int dtype, const ConvArgs& a_in, hipStream_t st) {
   { static const int dbg = getenv("SIDEKIT_AMD_CONV_DBG") ? atoi(getenv("SIDEKIT_AMD_CONV_DBG")) : 0; a.dbg |= dbg; }   // diagnostics only: the ablation bits of sk_bench_conv for every convolution of a forward
   switch (shape) {
 #define X(id, name) \
-  case id: return dtype == DT_BF16 ? launch_cfg<B_##name>(a, st) : launch_cfg<F_##name>(a, st);
+  case id: return dtype == DT_BF16 ? launch_cfg<B_##name, ((id) < (int)CONV_NSHAPES)>(a, st) : launch_cfg<F_##name, ((id) < (int)CONV_NSHAPES)>(a, st);
     SK_CONV_CASES(X)
 #undef X
   }

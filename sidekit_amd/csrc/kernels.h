@@ -50,6 +50,10 @@ struct ConvArgs {
   int B, Hin, Hout;    // allocated rows of in / out
   int relu;
   int persist_cap;     // > 0: at most this many workgroups per CU for the persistent (weight-resident) shapes, see launch_cfg
+  // -- residual mode with the SE gate computed in this kernel's prologue (gate_pro != 0; small grids only, se_gate_inl.h): `gate` is not read,
+  //    every workgroup derives its utterance's gate from conv1's sums (`se`, what launch_se_pre would have been handed)
+  int gate_pro;
+  SeArgs se;
   unsigned long long* stamps;  // diagnostics only: per-workgroup s_memtime stamps at the phase boundaries (8 per block), or nullptr
   int dbg;             // diagnostics only (sk_bench_conv): bit0 skip stores, bit1 skip MFMA loop, bit2 skip staging
 };

@@ -109,6 +109,10 @@ struct xt_handle {
   bool shortcut_tensor = getenv("SIDEKIT_AMD_SHORTCUT_TENSOR") != nullptr;   // A/B switch, see half_from_feats
   bool mel_gemm = getenv("SIDEKIT_AMD_MEL_GEMM") != nullptr;                 // A/B switch: mel projection as a separate GEMM
   bool mfcc_dft_gemm = getenv("SIDEKIT_AMD_MFCC_DFT_GEMM") != nullptr;       // A/B switch: MFCC spectrum as a DFT contraction (round-1 form) instead of the FFT
+  // SE gate in conv2's prologue instead of a launch of its own (se_gate_inl.h): 1 (default) for small grids -- at most 8 utterances and 1024
+  // row tiles, where a forward is a chain of dependent launches and the launch is what the gate costs --, 0 never, 2 always (A/B and the
+  // bit-identity test: the two constructions give the same gate bits at any batch size)
+  int gate_prologue = getenv("SIDEKIT_AMD_GATE_PROLOGUE") ? atoi(getenv("SIDEKIT_AMD_GATE_PROLOGUE")) : 1;
   xt_config cfg;
   int device = 0;
   bool finalized = false;
@@ -764,7 +768,8 @@ static int half_from_feats(xt_handle* h, Lane& ln, const float* feats, long sb, 
       a.se_part = nullptr; a.col_part = nullptr; a.edge = nullptr; a.relu = 0;
       { ProfScope ps(h, b.sc.shape, st); SK_TRY(launch_conv(b.sc.shape, dt, a, st)); }
     }
-    {
+    const bool gate_pro = h->gate_prologue == 2 || (h->gate_prologue == 1 && B <= 8 && (long)B * cdiv(Hl[li], b.c2.g.th) <= 1024);
+    if (!gate_pro) {
       ProfScope ps(h, XT_PROF_SE_RES, st);
       SK_TRY(launch_se_pre(se, st));
     }
@@ -772,6 +777,7 @@ static int half_from_feats(xt_handle* h, Lane& ln, const float* feats, long sb, 
     a.in = O1; a.wpack = b.c2.wpack; a.scale = b.c2.scale; a.shift = b.c2.shift; a.out = O2;
     a.se_part = nullptr; a.col_part = nullptr; a.edge = nullptr; a.gate = (const float*)ln.ws_gate.p; a.shortcut = shortcut;
     a.halvings_in = li; a.Hin = Hl[li]; a.Hout = Hl[li]; a.relu = 0;
+    if (gate_pro) { a.gate_pro = 1; a.se = se; }     // every workgroup of conv2 derives its utterance's gate itself; ws_gate is not read
     if (inplace_sc) {
       a.shortcut = nullptr; a.sc_in = X; a.sc_hin = Hl[lin];
       a.sc_wpack = b.sc_wfold; a.sc_scale = b.sc.scale; a.sc_shift = b.sc.shift;

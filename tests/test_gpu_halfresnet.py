@@ -295,6 +295,34 @@ def test_embedding_does_not_depend_on_the_batch_size(gpu):
         assert torch.equal(big, parts), (dt, float((big - parts).abs().max()))
 
 
+def test_gate_in_conv2s_prologue_gives_the_bits_of_the_gate_launch(gpu, monkeypatch):
+    """Small batches (<= 8 utterances) take their SE gates from conv2's prologue (csrc/se_gate_inl.h: every workgroup of an utterance walks the
+    1024 virtual threads of ``se_pre_kernel`` on its 256 real ones), larger ones from the launch of ``se_pre_kernel`` between conv1 and conv2
+    (sidekit/nnet/res_net.py:272-281,316-319).  Forced either way on two models with the same weights (SIDEKIT_AMD_GATE_PROLOGUE = 0 / 2),
+    x-vectors and logits are the same bits at every batch size -- batch 1 at 4 s and 45 s (563 row tiles: persistent workgroups walk several
+    tiles of the utterance), ragged batches, a batch of 40 -- in both precisions; and the automatic choice agrees with both."""
+    models = {}
+    for mode in ("0", "2", "1"):
+        monkeypatch.setenv("SIDEKIT_AMD_GATE_PROLOGUE", mode)
+        m = Xtractor(64, model_archi="halfresnet34", loss="aam", seed=41).to(gpu).eval()
+        m.compute_dtype = "fp32"; m(torch.zeros(1, 4000, device="cuda") + 0.01, is_eval=True)      # the handles are created under this setting
+        m.compute_dtype = "bf16"; m(torch.zeros(1, 4000, device="cuda") + 0.01, is_eval=True)
+        models[mode] = m
+    g = torch.Generator(device="cuda").manual_seed(17)
+    cases = [(1, 64000, False), (1, 45 * 16000, False), (3, 48000, True), (8, 64000, False), (8, 160000, True), (40, 32000, True)]
+    for B, L, ragged in cases:
+        wav = 0.1 * torch.randn(B, L, device="cuda", generator=g)
+        lens = torch.randint(L // 4, L + 1, (B,), generator=torch.Generator().manual_seed(B * 7 + 1)).tolist() if ragged else None
+        for dt in ("bf16", "fp32"):
+            outs = {}
+            for mode, m in models.items():
+                m.compute_dtype = dt
+                outs[mode] = m(wav, is_eval=True, lengths=lens)
+            for mode in ("2", "1"):
+                assert torch.equal(outs[mode][1], outs["0"][1]) and torch.equal(outs[mode][0], outs["0"][0]), (B, L, ragged, dt, mode)
+    torch.cuda.synchronize()
+
+
 def test_very_short_clips_as_the_first_call(gpu):
     """A batch of 0.05-0.16 s clips (6-16 frames: ONE row tile per layer, T' = 1-2) as a fresh model's first call -- the
     workspace is then sized by that shape alone (the SE-statistics buffers were once under-reserved for it) -- against each clip
