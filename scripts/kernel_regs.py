@@ -8,7 +8,7 @@ flt = sys.argv[2] if len(sys.argv) > 2 else ""
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 with tempfile.TemporaryDirectory() as d:
     out = os.path.join(d, "k.s")
-    subprocess.run(["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-mllvm", "-pragma-unroll-threshold=65536", "-I" + os.path.join(root, "include"),
+    subprocess.run(["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-slp-vectorize", "-mllvm", "-pragma-unroll-threshold=65536", "-I" + os.path.join(root, "include"),
                     "--offload-device-only", "-S", src, "-o", out], check=True, stderr=subprocess.DEVNULL)
     s = open(out).read()
 for m in re.finditer(r"\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel", s, re.S):

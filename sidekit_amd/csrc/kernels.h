@@ -9,7 +9,9 @@ enum { DT_F32 = 0, DT_BF16 = 1, DT_F64 = 2, DT_I64 = 3 };
 // ---- conv3x3.hip ------------------------------------------------------------------------
 enum ConvShape {
   CONV_L1 = 0, CONV_L1S, CONV_L2A, CONV_L2S, CONV_L2, CONV_L3A, CONV_L3S, CONV_L3, CONV_L4A, CONV_L4S, CONV_L4,
-  CONV_NSHAPES
+  CONV_NSHAPES,
+  // small-grid forms of CONV_L3 / CONV_L4 (conv3x3.hip: 3- / 5-row tiles, residual forms only; ids 11-41 and 44-46 are A/B alternatives)
+  CONV_L3T = 42, CONV_L4T = 43
 };
 
 struct SeArgs {

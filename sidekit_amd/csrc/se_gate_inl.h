@@ -19,33 +19,99 @@
 
 namespace sk {
 
+constexpr int se_rows_per_round(int nit) {   // the largest divisor of the trip count up to 24
+  for (int d = 24; d > 1; --d)
+    if (nit % d == 0) return d;
+  return 1;
+}
+
 template <typename WT, int C, int NT>
 __device__ __attribute__((always_inline)) inline void se_gate_block(const SeArgs a, int b, int tid, float* __restrict__ red, float* __restrict__ S, float* __restrict__ y,
                                      float* __restrict__ hid, float* __restrict__ gate_out) {
   static_assert(1024 % NT == 0 && NT >= C && NT >= 256, "virtual-thread walk: NT divides 1024 and covers the per-channel stages");
   constexpr int NV = 1024 / NT;
   constexpr int VEC = 16 / sizeof(WT), G = 1024 / C, R = C / 16;
+  constexpr int CG = C / VEC, KG = 1024 / CG, NIT = (9 * C + KG - 1) / KG;
+  // This runs on the critical path of a batch-1 forward with ONE wave per SIMD: it is written for few dependent round trips to L2, not for
+  // throughput.  Everything that does not depend on conv1's sums is requested first -- the FC matrices, conv2's BatchNorm constants and as
+  // many conv2-weight rows as the register file holds (the kernel owns all of it: one workgroup per CU) --, the sums of the NV virtual
+  // threads are requested together, and the weight rows travel in rounds of WCH loads.
+  constexpr int WCH = se_rows_per_round(NIT);        // rows per round and virtual thread: bf16 C <= 128 one round (2 / 5 / 18 rows), C = 256 three of 24
+  static_assert(NIT % WCH == 0, "weight rounds");
+  constexpr int NF = C * R, NPF = (NF + NT - 1) / NT;
+  constexpr bool FC_EARLY = NPF <= 4;                // C = 256 (16 + 16 registers beside two 96-register weight buffers) fetches them when phase 3 starts
+  float pf1[NPF], pf2[NPF];
+  if constexpr (FC_EARLY) {
+#pragma unroll
+    for (int i = 0; i < NPF; ++i) {
+      const int idx = tid + i * NT;
+      pf1[i] = idx < NF ? a.fc1[idx] : 0.f;
+      pf2[i] = idx < NF ? a.fc2[idx] : 0.f;
+    }
+  }
+  const float psc = a.scale2[tid < C ? tid : 0], psh = a.shift2[tid < C ? tid : 0];
+  const unsigned char* wbase = reinterpret_cast<const unsigned char*>(a.w2t);
+  constexpr bool EXACT = KG * NIT == 9 * C;          // every (virtual thread, row) is a row of the matrix: no bound check
+  auto wrow = [&](int j, int i) {                    // row i of virtual thread j: k = kg + i KG, this thread's 16 B of output channels
+    const int v = tid + j * NT, cg = v % CG, kg = v / CG, k = kg + i * KG;
+    // wave-uniform part (row block i) + 32-bit lane part: one address register per virtual thread instead of a 64-bit pair per row
+    const unsigned lane_off = (unsigned)kg * (unsigned)(C * sizeof(WT)) + (unsigned)cg * 16u;
+    const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane(i * KG * C * (int)sizeof(WT));
+    const uint4 val = *reinterpret_cast<const uint4*>(wbase + soff + ((EXACT || k < 9 * C) ? lane_off : 0u));
+    return (EXACT || k < 9 * C) ? val : make_uint4(0, 0, 0, 0);
+  };
+  constexpr bool EARLY = NV * NIT <= 72 && WCH == NIT;             // every weight row of this thread in flight before the sums are (C <= 128: 8 / 20 / 72 x 16 B)
+  uint4 w[EARLY ? NV : 1][WCH];
+  if constexpr (EARLY) {
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+#pragma unroll
+      for (int i = 0; i < WCH; ++i) w[j][i] = wrow(j, i);
+  }
   const int hb = halve(a.lens.get_uniform(b), a.halvings);
   const int nt = (hb + a.th - 1) / a.th;
-  // ---- phase 1: conv1's per-tile sums -> S[9][C] (sums of the zero-padded plane shifted by each tap)
+  // ---- phase 1: conv1's per-tile sums -> S[9][C] (sums of the zero-padded plane shifted by each tap).  Virtual thread (c, g) adds the tiles
+  // t = g, g + G, ... in that order; the NV virtual threads of a lane advance together (a tile past the utterance's last adds +0.0f: the sums
+  // start at +0.0f, so that changes no bit)
+  {
+    float T[NV], C0[NV], CL[NV];
 #pragma unroll
-  for (int j = 0; j < NV; ++j) {
-    const int v = tid + j * NT, c = v % C, g = v / C;
-    float T = 0.f, C0 = 0.f, CL = 0.f;
-    for (int t = g; t < nt; t += G) {
-      for (int wv = 0; wv < a.wm; ++wv) T += a.se_part[(((size_t)b * a.tiles + t) * a.wm + wv) * C + c];
-      C0 += a.col_part[((size_t)b * a.tiles + t) * 2 * C + c];
-      CL += a.col_part[((size_t)b * a.tiles + t) * 2 * C + C + c];
+    for (int j = 0; j < NV; ++j) T[j] = C0[j] = CL[j] = 0.f;
+    for (int t0 = 0; t0 < nt; t0 += G) {
+      float vT[NV][4], vC0[NV], vCL[NV];
+#pragma unroll
+      for (int j = 0; j < NV; ++j) {
+        const int v = tid + j * NT, c = v % C, t = t0 + v / C;
+        const bool ok = t < nt;
+        const size_t tt = (size_t)b * a.tiles + (ok ? t : 0);
+#pragma unroll
+        for (int wv = 0; wv < 4; ++wv) vT[j][wv] = (ok && wv < a.wm) ? a.se_part[(tt * a.wm + (wv < a.wm ? wv : 0)) * C + c] : 0.f;
+        vC0[j] = ok ? a.col_part[tt * 2 * C + c] : 0.f;
+        vCL[j] = ok ? a.col_part[tt * 2 * C + C + c] : 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < NV; ++j) {
+#pragma unroll
+        for (int wv = 0; wv < 4; ++wv) T[j] += vT[j][wv];      // wm <= 4 wave rows; the rows past wm add +0.0f
+        C0[j] += vC0[j];
+        CL[j] += vCL[j];
+      }
     }
-    red[v] = T; red[1024 + v] = C0; red[2048 + v] = CL;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) { const int v = tid + j * NT; red[v] = T[j]; red[1024 + v] = C0[j]; red[2048 + v] = CL[j]; }
+  }
+  float eg6[6];
+  if (tid < C) {
+    const float* eg = a.edge + (size_t)b * 6 * C + tid;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) eg6[q] = eg[q * C];
   }
   __syncthreads();
   if (tid < C) {
     const int c = tid;
     float T = 0.f, C0 = 0.f, CL = 0.f;
     for (int q = 0; q < G; ++q) { T += red[q * C + c]; C0 += red[1024 + q * C + c]; CL += red[2048 + q * C + c]; }
-    const float* eg = a.edge + (size_t)b * 6 * C + c;
-    const float R0 = eg[0], RL = eg[C], k00 = eg[2 * C], k0L = eg[3 * C], kL0 = eg[4 * C], kLL = eg[5 * C];
+    const float R0 = eg6[0], RL = eg6[1], k00 = eg6[2], k0L = eg6[3], kL0 = eg6[4], kLL = eg6[5];
 #pragma unroll
     for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
@@ -57,45 +123,68 @@ __device__ __attribute__((always_inline)) inline void se_gate_block(const SeArgs
       }
   }
   __syncthreads();
-  // ---- phase 2: S contracted with conv2's weights; virtual thread (cg, kg) owns 16 B of output channels and the rows k = kg + i KG
-  constexpr int CG = C / VEC, KG = 1024 / CG, NIT = (9 * C + KG - 1) / KG;
-  constexpr int CH = NIT % 12 == 0 ? 12 : (NIT % 9 == 0 ? 9 : (NIT % 8 == 0 ? 8 : (NIT % 6 == 0 ? 6 : (NIT % 4 == 0 ? 4 : (NIT % 3 == 0 ? 3 : (NIT % 2 == 0 ? 2 : 1))))));   // loads in flight per round
-  const unsigned char* wbase = reinterpret_cast<const unsigned char*>(a.w2t);
-#pragma unroll 1
-  for (int j = 0; j < NV; ++j) {
-    const int v = tid + j * NT, cg = v % CG, kg = v / CG;
-    const unsigned char* wp = wbase + (size_t)cg * 16;
-    float m[VEC];
+  // ---- phase 2: S contracted with conv2's weights; virtual thread (cg, kg) owns 16 B of output channels and the rows k = kg + i KG, i ascending
+  auto fma_row = [&](float* m, const uint4& wv, int k) {
+    if (k < 9 * C) {
+      const float s = S[k];
+      const uint32_t ww[4] = {wv.x, wv.y, wv.z, wv.w};
 #pragma unroll
-    for (int q = 0; q < VEC; ++q) m[q] = 0.f;
-#pragma unroll 1
-    for (int i0 = 0; i0 < NIT; i0 += CH) {
-      uint4 w[CH];
-#pragma unroll
-      for (int i = 0; i < CH; ++i) {
-        const int k = kg + (i0 + i) * KG;
-        w[i] = k < 9 * C ? *reinterpret_cast<const uint4*>(wp + (size_t)k * C * sizeof(WT)) : make_uint4(0, 0, 0, 0);
-      }
-#pragma unroll
-      for (int i = 0; i < CH; ++i) {
-        const int k = kg + (i0 + i) * KG;
-        if (k < 9 * C) {
-          const float s = S[k];
-          const uint32_t ww[4] = {w[i].x, w[i].y, w[i].z, w[i].w};
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            if constexpr (sizeof(WT) == 2) {
-              m[2 * q] = fmaf(bf16_to_f32((uint16_t)(ww[q] & 0xffff)), s, m[2 * q]);
-              m[2 * q + 1] = fmaf(bf16_to_f32((uint16_t)(ww[q] >> 16)), s, m[2 * q + 1]);
-            } else {
-              m[q] = fmaf(__builtin_bit_cast(float, ww[q]), s, m[q]);
-            }
-          }
+      for (int q = 0; q < 4; ++q) {
+        if constexpr (sizeof(WT) == 2) {
+          m[2 * q] = fmaf(bf16_to_f32((uint16_t)(ww[q] & 0xffff)), s, m[2 * q]);
+          m[2 * q + 1] = fmaf(bf16_to_f32((uint16_t)(ww[q] >> 16)), s, m[2 * q + 1]);
+        } else {
+          m[q] = fmaf(__builtin_bit_cast(float, ww[q]), s, m[q]);
         }
       }
     }
+  };
+  if constexpr (EARLY) {
 #pragma unroll
-    for (int q = 0; q < VEC; ++q) red[kg * C + cg * VEC + q] = m[q];
+    for (int j = 0; j < NV; ++j) {
+      const int v = tid + j * NT, cg = v % CG, kg = v / CG;
+      float m[VEC];
+#pragma unroll
+      for (int q = 0; q < VEC; ++q) m[q] = 0.f;
+#pragma unroll
+      for (int i = 0; i < WCH; ++i) fma_row(m, w[j][i], kg + i * KG);
+#pragma unroll
+      for (int q = 0; q < VEC; ++q) red[kg * C + cg * VEC + q] = m[q];
+    }
+  } else {
+    // C = 256: 288 rows of 16 B per thread -- rounds of WCH rows through two register buffers, the next round requested before this one is
+    // consumed; rolled (two rounds per trip), the round index decides which virtual thread and which rows
+    constexpr int RPJ = NIT / WCH, NRND = NV * RPJ;
+    static_assert(NRND % 2 == 0, "two rounds per trip");
+    uint4 wa[WCH], wb[WCH];
+    float m[VEC];
+    auto request = [&](uint4* buf, int rnd) {
+      const int j = rnd / RPJ, i0 = (rnd % RPJ) * WCH;
+#pragma unroll
+      for (int i = 0; i < WCH; ++i) buf[i] = wrow(j, i0 + i);
+    };
+    auto consume = [&](const uint4* buf, int rnd) {
+      const int j = rnd / RPJ, i0 = (rnd % RPJ) * WCH;
+      const int v = tid + j * NT, cg = v % CG, kg = v / CG;
+      if (i0 == 0) {
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) m[q] = 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < WCH; ++i) fma_row(m, buf[i], kg + (i0 + i) * KG);
+      if (i0 + WCH == NIT) {
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) red[kg * C + cg * VEC + q] = m[q];
+      }
+    };
+    request(wa, 0);
+#pragma unroll 1
+    for (int rnd = 0; rnd < NRND; rnd += 2) {
+      request(wb, rnd + 1);
+      consume(wa, rnd);
+      if (rnd + 2 < NRND) request(wa, rnd + 2);
+      consume(wb, rnd + 1);
+    }
   }
   __syncthreads();
   {  // the KG row-group partials of a channel meet in two stages, as in se_pre_kernel
@@ -114,13 +203,17 @@ __device__ __attribute__((always_inline)) inline void se_gate_block(const SeArgs
     if (tid < C) {
       float t = 0.f;
       for (int q = 0; q < G; ++q) t += red[q * C + tid];
-      y[tid] = t / (float)(hb * a.wout) * a.scale2[tid] + a.shift2[tid];
+      y[tid] = t / (float)(hb * a.wout) * psc + psh;
     }
   }
   __syncthreads();
   // ---- phase 3: FC -> ReLU -> FC -> sigmoid.  fc1 [R][C] at red[0 ..), fc2 [C][R] at red[4096 ..)
-  constexpr int NF = C * R;
-  for (int idx = tid; idx < NF; idx += NT) { red[idx] = a.fc1[idx]; red[4096 + idx] = a.fc2[idx]; }
+#pragma unroll
+  for (int i = 0; i < NPF; ++i) {
+    const int idx = tid + i * NT;
+    if constexpr (!FC_EARLY) { pf1[i] = idx < NF ? a.fc1[idx] : 0.f; pf2[i] = idx < NF ? a.fc2[idx] : 0.f; }
+    if (idx < NF) { red[idx] = pf1[i]; red[4096 + idx] = pf2[i]; }
+  }
   __syncthreads();
   {
     constexpr int NS = C / 16;                       // R * NS = C * C / 256 <= 256 virtual threads: all of them real

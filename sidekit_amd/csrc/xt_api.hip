@@ -109,10 +109,14 @@ struct xt_handle {
   bool shortcut_tensor = getenv("SIDEKIT_AMD_SHORTCUT_TENSOR") != nullptr;   // A/B switch, see half_from_feats
   bool mel_gemm = getenv("SIDEKIT_AMD_MEL_GEMM") != nullptr;                 // A/B switch: mel projection as a separate GEMM
   bool mfcc_dft_gemm = getenv("SIDEKIT_AMD_MFCC_DFT_GEMM") != nullptr;       // A/B switch: MFCC spectrum as a DFT contraction (round-1 form) instead of the FFT
-  // SE gate in conv2's prologue instead of a launch of its own (se_gate_inl.h): 1 (default) for small grids -- at most 8 utterances and 1024
-  // row tiles, where a forward is a chain of dependent launches and the launch is what the gate costs --, 0 never, 2 always (A/B and the
-  // bit-identity test: the two constructions give the same gate bits at any batch size)
-  int gate_prologue = getenv("SIDEKIT_AMD_GATE_PROLOGUE") ? atoi(getenv("SIDEKIT_AMD_GATE_PROLOGUE")) : 1;
+  // SE gate in conv2's prologue instead of a launch of its own (se_gate_inl.h): 0 (default) never, 1 for small grids (at most 8 utterances), 2 always.
+  // Built and measured as the round-4 verdict specified it (separate instantiation, every workgroup of an utterance reduces the sums in
+  // se_pre_kernel's order: bit-identical, tests/test_gpu_halfresnet.py) -- and it does not pay: the gate is a chain of dependent L2 round trips
+  // and barriers that takes 5-6 us whether it runs as a kernel (5.7-7.3 us, floor of a dependent launch included) or at the head of conv2
+  // (+5.4-6.3 us per conv2, +23 us for layer 4): 0.690 vs 0.687 ms per 4-s utterance, profiles/r05_latency_matrix.txt.  Off; kept for A/B.
+  int gate_prologue = getenv("SIDEKIT_AMD_GATE_PROLOGUE") ? atoi(getenv("SIDEKIT_AMD_GATE_PROLOGUE")) : 0;
+  // small-grid tilings for conv2 of layers 3-4 (conv3x3.hip, "Small-grid forms"): 1 (default) at most 8 utterances, 0 never, 2 always
+  int small_grid = getenv("SIDEKIT_AMD_SMALL_GRID") ? atoi(getenv("SIDEKIT_AMD_SMALL_GRID")) : 1;
   xt_config cfg;
   int device = 0;
   bool finalized = false;
@@ -768,7 +772,11 @@ static int half_from_feats(xt_handle* h, Lane& ln, const float* feats, long sb, 
       a.se_part = nullptr; a.col_part = nullptr; a.edge = nullptr; a.relu = 0;
       { ProfScope ps(h, b.sc.shape, st); SK_TRY(launch_conv(b.sc.shape, dt, a, st)); }
     }
-    const bool gate_pro = h->gate_prologue == 2 || (h->gate_prologue == 1 && B <= 8 && (long)B * cdiv(Hl[li], b.c2.g.th) <= 1024);
+    // small grids (at most 8 utterances: the reference driver's one-utterance-at-a-time call shape, sidekit/bin/extract_xvectors.py:146): a forward is a
+    // chain of dependent launches, each as long as ONE wave's work: conv2 of layers 3-4 runs in 3- / 5-row tiles (more, shorter workgroups).  Same bits.
+    const bool small = dt == DT_BF16 && (h->small_grid == 2 || (h->small_grid == 1 && B <= 8 && (long)B * Hl[li] <= 4096));
+    const int c2shape = !small ? b.c2.shape : (li == 2 ? (int)CONV_L3T : (li == 3 ? (int)CONV_L4T : b.c2.shape));
+    const bool gate_pro = h->gate_prologue == 2 || (h->gate_prologue == 1 && B <= 8 && (long)B * Hl[li] <= 4096);
     if (!gate_pro) {
       ProfScope ps(h, XT_PROF_SE_RES, st);
       SK_TRY(launch_se_pre(se, st));
@@ -782,7 +790,7 @@ static int half_from_feats(xt_handle* h, Lane& ln, const float* feats, long sb, 
       a.shortcut = nullptr; a.sc_in = X; a.sc_hin = Hl[lin];
       a.sc_wpack = b.sc_wfold; a.sc_scale = b.sc.scale; a.sc_shift = b.sc.shift;
     }
-    { ProfScope ps(h, b.c2.shape, st); SK_TRY(launch_conv(b.c2.shape, dt, a, st)); }
+    { ProfScope ps(h, b.c2.shape, st); SK_TRY(launch_conv(c2shape, dt, a, st)); }
     std::swap(X, O2);
     const bool last_of_layer = (bi + 1 == h->blocks.size()) || (h->blocks[bi + 1].li != li);
     if (last_of_layer) {

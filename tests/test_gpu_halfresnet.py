@@ -267,12 +267,15 @@ def test_ab_paths_agree(gpu, monkeypatch):
 
 def test_profile_slots(model):
     """xt_set_profile: every kernel class, or only the named ones (bench.py brackets the dominant class in its timed region)."""
-    wav = 0.1 * torch.randn(2, 16000).cuda()
+    wav = 0.1 * torch.randn(16, 16000).cuda()
     model.set_profile(True)
     model.get_profile(reset=True)
     model(wav, is_eval=True)
     full = model.get_profile(reset=True)
-    assert {"conv_L1", "conv_L4", "frontend", "stem", "se_residual", "pool_tail"} <= set(full) and full["conv_L1"][1] == 6
+    assert {"conv_L1", "conv_L4", "frontend", "stem", "se_residual", "pool_tail"} <= set(full) and full["conv_L1"][1] == 6 and full["se_residual"][1] == 16
+    model(wav[:2], is_eval=True)                      # at most 8 utterances: conv2 of layers 3-4 runs its small-grid tiling, booked under the same class
+    small = model.get_profile(reset=True)
+    assert small["se_residual"][1] == 16 and small["conv_L1"][1] == 6 and small["conv_L3"][1] == 11 and small["conv_L4"][1] == 5
     model.set_profile(True, slots=["stem", "conv_L3"])
     model(wav, is_eval=True)
     part = model.get_profile(reset=True)
@@ -295,15 +298,18 @@ def test_embedding_does_not_depend_on_the_batch_size(gpu):
         assert torch.equal(big, parts), (dt, float((big - parts).abs().max()))
 
 
-def test_gate_in_conv2s_prologue_gives_the_bits_of_the_gate_launch(gpu, monkeypatch):
-    """Small batches (<= 8 utterances) take their SE gates from conv2's prologue (csrc/se_gate_inl.h: every workgroup of an utterance walks the
-    1024 virtual threads of ``se_pre_kernel`` on its 256 real ones), larger ones from the launch of ``se_pre_kernel`` between conv1 and conv2
-    (sidekit/nnet/res_net.py:272-281,316-319).  Forced either way on two models with the same weights (SIDEKIT_AMD_GATE_PROLOGUE = 0 / 2),
-    x-vectors and logits are the same bits at every batch size -- batch 1 at 4 s and 45 s (563 row tiles: persistent workgroups walk several
-    tiles of the utterance), ragged batches, a batch of 40 -- in both precisions; and the automatic choice agrees with both."""
+def test_small_grid_forms_give_the_bits_of_the_batch_forms(gpu, monkeypatch):
+    """Small batches (<= 8 utterances: the reference driver's call shape, sidekit/bin/extract_xvectors.py:146) run layers 2-4 on their small-grid
+    convolution shapes (deep weight rings, conv2 of layers 3-4 in 3- / 5-row tiles: csrc/conv3x3.hip) and may take their SE gates from conv2's
+    prologue (csrc/se_gate_inl.h: every workgroup of an utterance walks the 1024 virtual threads of ``se_pre_kernel`` on its 256 real ones)
+    instead of the launch of ``se_pre_kernel`` between conv1 and conv2 (sidekit/nnet/res_net.py:272-281,316-319).  Forced either way on
+    models with the same weights (SIDEKIT_AMD_SMALL_GRID / _GATE_PROLOGUE = 0 / 2), x-vectors and logits are the same bits at every batch
+    size -- batch 1 at 4 s and 45 s (563 row tiles: persistent workgroups walk several tiles of the utterance), ragged batches, a batch of 40
+    -- in both precisions; and the automatic choice agrees with both."""
     models = {}
     for mode in ("0", "2", "1"):
         monkeypatch.setenv("SIDEKIT_AMD_GATE_PROLOGUE", mode)
+        monkeypatch.setenv("SIDEKIT_AMD_SMALL_GRID", mode)
         m = Xtractor(64, model_archi="halfresnet34", loss="aam", seed=41).to(gpu).eval()
         m.compute_dtype = "fp32"; m(torch.zeros(1, 4000, device="cuda") + 0.01, is_eval=True)      # the handles are created under this setting
         m.compute_dtype = "bf16"; m(torch.zeros(1, 4000, device="cuda") + 0.01, is_eval=True)
