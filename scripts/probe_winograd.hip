@@ -1,0 +1,211 @@
+// Probe (diagnostic, not part of the library): the inner loop of Winograd F(2x2, 3x3) for the layer-3 convolution shape (C = 128 in / out, W = 20,
+// bf16 operands, f32 accumulation) in the largest mapping a CU's registers hold, MEASURED instead of priced (round-5 verdict item 2) -- beside the
+// product's direct kernel (sk_bench_conv shape CONV_L3, scripts/conv_bench.py) on the same problem size.
+//
+// Mapping (one workgroup = 4 waves, one per SIMD, the whole register file): 32 Winograd tiles = 128 output positions (8 rows x 16 columns) x
+// all 128 output channels.  Wave (g, h) owns tile group g (16 tiles = the 16 positions of a 16x16x32 MFMA) and output-channel half h (4 tiles of
+// 16 channels) for ALL 16 transform positions: 16 x 4 accumulator tiles = 256 registers -- the reason no more tiles fit (48 tiles would be 384
+// accumulator registers + operands), and with them no more reuse of a weight fragment.  Per k-step (32 input channels) a lane reads the 4 x 4
+// input patch of its tile for its 8 channels from the staged halo tile (16 x ds_read_b128), transforms it in f32 (B' d B: widen, 2 x 32
+// adds / subs per channel, plain VOP2 -- no packed f32) and rounds to bf16: the 16 MFMA operands V; then 16 x 4 MFMAs, each with its OWN 1-KB
+// fragment of the transformed weights U = G g G' (16 x the 128 x 128 matrix = 524 KB, L2 resident) -- one global load per MFMA, where the direct
+// kernel has one per ten.  After the four k-steps: output transform A' M A on the accumulators (24 adds per 16 values), ReLU, bf16 store.
+//   MODE 0: every wave transforms all 16 positions itself (448 VALU instructions per k-step)
+//   MODE 1: the two waves of a tile group split the transform by rows of B' d and exchange halves through LDS (256 VALU + 8 + 8 LDS)
+//   MODE 2: MODE 1 without the weight loads (fragments stay in registers): what the L2 -> CU weight stream costs
+//   MODE 3: MODE 0 without the MFMAs: the transform + operand traffic alone
+// Arithmetic is real (random bf16 data, every result stored) but it is NOT a convolution: tiles index the staged buffer without halo logic.
+//   hipcc -O3 --offload-arch=gfx950 -fno-slp-vectorize scripts/probe_winograd.hip -o gpurun_out/probe_winograd && gpurun_out/probe_winograd
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <type_traits>
+#include <vector>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
+
+__device__ inline uint32_t pack2(float lo, float hi) {
+  const f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+}
+
+constexpr int ROWS = 10, COLS = 18, CH = 128;               // staged halo tile: (8 + 2) x (16 + 2) positions x 128 channels, 256 B each
+constexpr int TILE_BYTES = ROWS * COLS * CH * 2;            // 46 080 B
+
+template <int MODE>
+__global__ __launch_bounds__(256, 1) void wino_probe(const uint4* __restrict__ x, const uint4* __restrict__ U, uint2* __restrict__ out, int ntiles) {
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[TILE_BYTES];
+  __shared__ __attribute__((aligned(16))) uint4 xch[MODE == 1 || MODE == 2 ? 4 * 8 * 64 : 1];   // MODE 1 / 2: the halves of V the wave pairs exchange
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = __builtin_amdgcn_readfirstlane(wave >> 1), h = __builtin_amdgcn_readfirstlane(wave & 1);   // tile group, output-channel half
+  const int p = lane & 15, q = lane >> 4;                    // MFMA position (tile) and 8-channel chunk of a 32-channel k-step
+  const int trow = g * 2 + (p >> 3), tcol = p & 7;           // tile (row, col) inside the 4 x 8 tile block
+  for (int wi = blockIdx.x; wi < ntiles; wi += gridDim.x) {
+    __syncthreads();
+    for (int i = tid; i < TILE_BYTES / 16; i += 256) reinterpret_cast<uint4*>(smem)[i] = x[((size_t)wi * (TILE_BYTES / 16) + i) & ((1u << 22) - 1)];
+    __syncthreads();
+    f32x4 acc[16][4];
+#pragma unroll
+    for (int z = 0; z < 16; ++z)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[z][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    uint4 wreg[MODE == 2 ? 4 : 1];
+    if constexpr (MODE == 2) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) wreg[c] = U[(size_t)c * 64 + lane];
+    }
+#pragma unroll 1
+    for (int s = 0; s < 4; ++s) {
+      // ---- input transform: this lane's 4 x 4 patch, 8 channels, four channels at a time (64 instead of 128 registers of widened input)
+      uint4 V[16];
+      constexpr bool SPLIT = MODE == 1 || MODE == 2;
+      auto transform = [&](auto hsel) {
+        constexpr int HS = decltype(hsel)::value;            // -1: all four rows of B' d B; 0 / 1: rows 2 HS, 2 HS + 1 (patch rows HS .. HS + 2)
+        constexpr int R0 = HS < 0 ? 0 : HS, NR = HS < 0 ? 4 : 3;
+        uint32_t vp[16][4];
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          float d[NR][4][4];
+#pragma unroll
+          for (int i = 0; i < NR; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const uint2 v = *reinterpret_cast<const uint2*>(smem + (((2 * trow + R0 + i) * COLS + 2 * tcol + j) * CH + s * 32 + q * 8 + half * 4) * 2);
+              d[i][j][0] = __builtin_bit_cast(float, v.x << 16); d[i][j][1] = __builtin_bit_cast(float, v.x & 0xffff0000u);
+              d[i][j][2] = __builtin_bit_cast(float, v.y << 16); d[i][j][3] = __builtin_bit_cast(float, v.y & 0xffff0000u);
+            }
+#pragma unroll
+          for (int xi = 0; xi < 4; ++xi) {
+            if (HS >= 0 && (xi >> 1) != HS) continue;
+            float t[4][4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+              for (int c = 0; c < 4; ++c)   // B' d: r0 = d0 - d2, r1 = d1 + d2, r2 = d2 - d1, r3 = d1 - d3 (patch row index minus R0)
+                t[j][c] = xi == 0 ? d[0 - R0][j][c] - d[2 - R0][j][c] : (xi == 1 ? d[1 - R0][j][c] + d[2 - R0][j][c] : (xi == 2 ? d[2 - R0][j][c] - d[1 - R0][j][c] : d[1 - R0][j][c] - d[3 - R0][j][c]));
+#pragma unroll
+            for (int nu = 0; nu < 4; ++nu) {
+              float o[4];
+#pragma unroll
+              for (int c = 0; c < 4; ++c)
+                o[c] = nu == 0 ? t[0][c] - t[2][c] : (nu == 1 ? t[1][c] + t[2][c] : (nu == 2 ? t[2][c] - t[1][c] : t[1][c] - t[3][c]));
+              vp[xi * 4 + nu][half * 2] = pack2(o[0], o[1]);
+              vp[xi * 4 + nu][half * 2 + 1] = pack2(o[2], o[3]);
+            }
+          }
+        }
+#pragma unroll
+        for (int z = 0; z < 16; ++z)
+          if (HS < 0 || (z >> 3) == HS) V[z] = make_uint4(vp[z][0], vp[z][1], vp[z][2], vp[z][3]);
+      };
+      if constexpr (!SPLIT) transform(std::integral_constant<int, -1>{});
+      else if (h == 0) transform(std::integral_constant<int, 0>{});      // wave-uniform: a scalar branch, two copies of the code
+      else transform(std::integral_constant<int, 1>{});
+      if constexpr (SPLIT) {                                  // exchange: each wave of the pair publishes its 8 operands, reads the partner's 8
+        auto exchange = [&](auto hsel) {
+          constexpr int HS = decltype(hsel)::value;
+#pragma unroll
+          for (int z = 0; z < 8; ++z) xch[((g * 2 + HS) * 8 + z) * 64 + lane] = V[HS * 8 + z];
+          __syncthreads();
+#pragma unroll
+          for (int z = 0; z < 8; ++z) V[(1 - HS) * 8 + z] = xch[((g * 2 + (1 - HS)) * 8 + z) * 64 + lane];
+          __syncthreads();
+        };
+        if (h == 0) exchange(std::integral_constant<int, 0>{}); else exchange(std::integral_constant<int, 1>{});
+      }
+      // ---- 16 x 4 MFMAs, one weight fragment each
+#pragma unroll
+      for (int z = 0; z < 16; ++z) {
+        uint4 wf[4];
+        if constexpr (MODE != 2) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) wf[c] = U[((((size_t)z * 8 + h * 4 + c) * 4 + s) * 64) + lane];   // U[z][co tile][k-step][lane]: 1 KB per fragment
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          if constexpr (MODE == 3) {
+            acc[z][c][0] += __builtin_bit_cast(float, wf[c].x ^ V[z].x);
+          } else {
+            acc[z][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, MODE == 2 ? wreg[c] : wf[c]), __builtin_bit_cast(bf16x8, V[z]), acc[z][c], 0, 0, 0);
+          }
+        }
+      }
+    }
+    // ---- output transform A' M A (rows: y0 = m0 + m1 + m2, y1 = m1 - m2 - m3), ReLU, bf16 store: 4 outputs x 4 channels per (lane, channel tile)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      f32x4 tt[2][4];
+#pragma unroll
+      for (int nu = 0; nu < 4; ++nu) {
+        tt[0][nu] = acc[0 * 4 + nu][c] + acc[1 * 4 + nu][c] + acc[2 * 4 + nu][c];
+        tt[1][nu] = acc[1 * 4 + nu][c] - acc[2 * 4 + nu][c] - acc[3 * 4 + nu][c];
+      }
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        const f32x4 y0 = tt[a][0] + tt[a][1] + tt[a][2], y1 = tt[a][1] - tt[a][2] - tt[a][3];
+        const size_t pos = ((size_t)wi * 8 + 2 * trow + a) * 16 + 2 * tcol;
+        const size_t o = (pos * CH + (h * 4 + c) * 16 + q * 4) / 4;
+        out[o & ((1u << 24) - 1)] = make_uint2(pack2(fmaxf(y0[0], 0.f), fmaxf(y0[1], 0.f)), pack2(fmaxf(y0[2], 0.f), fmaxf(y0[3], 0.f)));
+        out[(o + CH / 4) & ((1u << 24) - 1)] = make_uint2(pack2(fmaxf(y1[0], 0.f), fmaxf(y1[1], 0.f)), pack2(fmaxf(y1[2], 0.f), fmaxf(y1[3], 0.f)));
+      }
+    }
+  }
+}
+
+template <int MODE>
+static int run(const char* name, const uint4* x, const uint4* U, uint2* out, int ntiles, int seconds) {
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  int cus = 256;
+  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0);
+  const int grid = ntiles < 8 * cus ? ntiles : ntiles;      // one work item per workgroup, like the product's layer-3 kernel
+  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(wino_probe<MODE>, dim3(grid), dim3(256), 0, 0, x, U, out, ntiles);
+  CK(hipDeviceSynchronize());
+  const int iters = 200;
+  double best = 1e9, sum = 0; int n = 0;
+  const double t_end = seconds;
+  double elapsed = 0;
+  while (elapsed < t_end) {
+    CK(hipEventRecord(e0, 0));
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(wino_probe<MODE>, dim3(grid), dim3(256), 0, 0, x, U, out, ntiles);
+    CK(hipEventRecord(e1, 0));
+    CK(hipEventSynchronize(e1));
+    float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
+    const double us = ms * 1e3 / iters;
+    best = us < best ? us : best; sum += us; ++n; elapsed += ms * 1e-3;
+  }
+  // one "launch" covers ntiles x 128 output positions x 128 channels; the layer-3 convolution at B = 256, T' = 101 is 256 * 101 * 20 positions
+  const double positions = (double)ntiles * 128.0;
+  printf("%-58s %8.1f us per launch (best %8.1f) = %6.3f ns per output position, direct-equivalent %6.2f PFLOP/s\n", name, sum / n, best, sum / n * 1e3 / positions,
+         positions * 128.0 * 128.0 * 9.0 * 2.0 / (sum / n * 1e-6) / 1e15);
+  fflush(stdout);
+  return 0;
+}
+
+int main(int argc, char** argv) {
+  const int seconds = argc > 1 ? atoi(argv[1]) : 3;
+  const int only = argc > 2 ? atoi(argv[2]) : -1;
+  const int ntiles = 256 * 101 * 20 / 128;                  // 4040 workgroups of 128 positions = the layer-3 launch of the benchmark batch
+  uint4 *x = nullptr, *U = nullptr; uint2* out = nullptr;
+  CK(hipMalloc(&x, (size_t)64 << 20)); CK(hipMalloc(&U, 524288 + 4096)); CK(hipMalloc(&out, (size_t)128 << 20));
+  {
+    std::vector<uint32_t> hbuf((64u << 20) / 4);
+    uint32_t s = 0x9E3779B9u;
+    auto bf = [&]() { s = s * 1664525u + 1013904223u; const uint32_t m = (s >> 9) & 0x7f, sg = (s >> 3) & 0x8000u, ex = 0x3e80u + (((s >> 20) & 3) << 7); return sg | ex | m; };   // bf16 in +-[0.25, 2)
+    for (auto& v : hbuf) v = bf() | (bf() << 16);
+    CK(hipMemcpy(x, hbuf.data(), (size_t)64 << 20, hipMemcpyHostToDevice));
+    CK(hipMemcpy(U, hbuf.data() + 12345, 524288, hipMemcpyHostToDevice));
+  }
+  printf("Winograd F(2x2,3x3) inner-loop probe, layer-3 shape (C = 128, 4040 workgroups x 128 positions), %d s per mode\n", seconds);
+  if (only < 0 || only == 0) run<0>("MODE 0: full transform per wave, weights from L2", x, U, out, ntiles, seconds);
+  if (only < 0 || only == 1) run<1>("MODE 1: transform split over the wave pair (LDS exchange)", x, U, out, ntiles, seconds);
+  if (only < 0 || only == 2) run<2>("MODE 2: as 1, weight fragments held in registers", x, U, out, ntiles, seconds);
+  if (only < 0 || only == 3) run<3>("MODE 3: as 0, no MFMAs (transform + operand traffic)", x, U, out, ntiles, seconds);
+  return 0;
+}
