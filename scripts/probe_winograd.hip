@@ -40,16 +40,27 @@ constexpr int TILE_BYTES = ROWS * COLS * CH * 2;            // 46 080 B
 
 template <int MODE>
 __global__ __launch_bounds__(256, 1) void wino_probe(const uint4* __restrict__ x, const uint4* __restrict__ U, uint2* __restrict__ out, int ntiles) {
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[TILE_BYTES];
+  __shared__ __attribute__((aligned(1024))) unsigned char smem2[2][TILE_BYTES];   // two halo tiles: the next work item's tile is DMA'ed while this one is computed
   __shared__ __attribute__((aligned(16))) uint4 xch[MODE == 1 || MODE == 2 ? 4 * 8 * 64 : 1];   // MODE 1 / 2: the halves of V the wave pairs exchange
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = __builtin_amdgcn_readfirstlane(wave >> 1), h = __builtin_amdgcn_readfirstlane(wave & 1);   // tile group, output-channel half
   const int p = lane & 15, q = lane >> 4;                    // MFMA position (tile) and 8-channel chunk of a 32-channel k-step
   const int trow = g * 2 + (p >> 3), tcol = p & 7;           // tile (row, col) inside the 4 x 8 tile block
-  for (int wi = blockIdx.x; wi < ntiles; wi += gridDim.x) {
+  // LDS-DMA staging as in the product kernel (global_load_lds_dwordx4: 64 lanes x 16 B per instruction, no VGPRs, every piece in flight at once);
+  // one workgroup per CU (the register file allows no second), persistent, double-buffered: tile n + 1 lands while tile n is computed
+  auto stage = [&](int wi, int buf) {
+    for (int it = wave; it < TILE_BYTES / 1024; it += 4) {
+      const uint4* src = x + ((((size_t)wi * (TILE_BYTES / 16)) + it * 64 + lane) & ((1u << 22) - 1));
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)(smem2[buf] + it * 1024), 16, 0, 0);
+    }
+  };
+  int buf = 0;
+  if ((int)blockIdx.x < ntiles) stage(blockIdx.x, 0);
+  for (int wi = blockIdx.x; wi < ntiles; wi += gridDim.x, buf ^= 1) {
+    __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): this tile's DMA has landed (the output stores of the previous tile with it)
     __syncthreads();
-    for (int i = tid; i < TILE_BYTES / 16; i += 256) reinterpret_cast<uint4*>(smem)[i] = x[((size_t)wi * (TILE_BYTES / 16) + i) & ((1u << 22) - 1)];
-    __syncthreads();
+    if (wi + (int)gridDim.x < ntiles) stage(wi + gridDim.x, buf ^ 1);
+    const unsigned char* smem = smem2[buf];
     f32x4 acc[16][4];
 #pragma unroll
     for (int z = 0; z < 16; ++z)
@@ -76,7 +87,12 @@ __global__ __launch_bounds__(256, 1) void wino_probe(const uint4* __restrict__ x
           for (int i = 0; i < NR; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-              const uint2 v = *reinterpret_cast<const uint2*>(smem + (((2 * trow + R0 + i) * COLS + 2 * tcol + j) * CH + s * 32 + q * 8 + half * 4) * 2);
+              // swizzled image (as the product's): the 16-B chunk c of position (row, col) sits at slot c ^ key(row, col), key = 8 (row/2 & 1) + (col/2 & 7)
+              // -- the 16 tiles of a read group then hit 16 different slots under every patch offset -- and the two 8-B halves of a chunk are
+              // taken in opposite order by even and odd q, so that a 32-lane pass covers all 256 B of a bank row
+              const int row = 2 * trow + R0 + i, col = 2 * tcol + j;
+              const int key = (((row >> 1) & 1) << 3) | ((col >> 1) & 7);
+              const uint2 v = *reinterpret_cast<const uint2*>(smem + (row * COLS + col) * (CH * 2) + (((s * 4 + q) ^ key) << 4) + ((half ^ (q & 1)) << 3));
               d[i][j][0] = __builtin_bit_cast(float, v.x << 16); d[i][j][1] = __builtin_bit_cast(float, v.x & 0xffff0000u);
               d[i][j][2] = __builtin_bit_cast(float, v.y << 16); d[i][j][3] = __builtin_bit_cast(float, v.y & 0xffff0000u);
             }
@@ -164,7 +180,7 @@ static int run(const char* name, const uint4* x, const uint4* U, uint2* out, int
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   int cus = 256;
   (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0);
-  const int grid = ntiles < 8 * cus ? ntiles : ntiles;      // one work item per workgroup, like the product's layer-3 kernel
+  const int grid = ntiles < cus ? ntiles : cus;             // persistent: one workgroup per CU walks its share of the work items
   for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(wino_probe<MODE>, dim3(grid), dim3(256), 0, 0, x, U, out, ntiles);
   CK(hipDeviceSynchronize());
   const int iters = 200;
@@ -202,6 +218,7 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(x, hbuf.data(), (size_t)64 << 20, hipMemcpyHostToDevice));
     CK(hipMemcpy(U, hbuf.data() + 12345, 524288, hipMemcpyHostToDevice));
   }
+  printf("READY\n"); fflush(stdout);
   printf("Winograd F(2x2,3x3) inner-loop probe, layer-3 shape (C = 128, 4040 workgroups x 128 positions), %d s per mode\n", seconds);
   if (only < 0 || only == 0) run<0>("MODE 0: full transform per wave, weights from L2", x, U, out, ntiles, seconds);
   if (only < 0 || only == 1) run<1>("MODE 1: transform split over the wave pair (LDS exchange)", x, U, out, ntiles, seconds);
