@@ -11,7 +11,7 @@ enum ConvShape {
   CONV_L1 = 0, CONV_L1S, CONV_L2A, CONV_L2S, CONV_L2, CONV_L3A, CONV_L3S, CONV_L3, CONV_L4A, CONV_L4S, CONV_L4,
   CONV_NSHAPES,
   // small-grid forms of CONV_L3 / CONV_L4 (conv3x3.hip: 3- / 5-row tiles, residual forms only; ids 11-41 and 44-46 are A/B alternatives)
-  CONV_L3T = 42, CONV_L4T = 43
+  CONV_L3T = 42, CONV_L4T = 43, CONV_L1G = 47   // L1G: layer 1's residual forms beside a gate wave (weights through a ring instead of resident)
 };
 
 struct SeArgs {

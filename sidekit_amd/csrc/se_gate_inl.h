@@ -240,6 +240,168 @@ __device__ __attribute__((always_inline)) inline void se_gate_block(const SeArgs
   __syncthreads();
 }
 
+// The same gate on ONE wave (64 lanes walking 16 virtual threads each), for a wave that has nothing else to do: conv2's gate wave (conv3x3.hip,
+// GATEPRO == 2) computes it BESIDE the four waves that stage the tile and run the k-loop -- the chain of dependent L2 round trips that makes
+// the gate cost 5-6 us wherever it runs alone (profiles/r05_latency_matrix.txt) then costs nothing, because nobody waits for it before the
+// epilogue.  A single wave needs no barrier: LDS operations of one wave execute in order, so a write is visible to the wave's next read once
+// the compiler is kept from reordering them (wave_barrier) and the data has been returned (lgkmcnt).  Only C = 32 / 64 (layers 1-2): one
+// wave's VALU is enough for 9 C^2 = 9 216 / 36 864 MACs, not for layer 3's 147 456.
+__device__ inline void se_wave_sync() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+}
+
+template <typename WT, int C>
+__device__ __attribute__((always_inline)) inline void se_gate_wave(const SeArgs a, int b, int lane, float* __restrict__ red, float* __restrict__ S, float* __restrict__ y,
+                                    float* __restrict__ hid, float* __restrict__ gate_out) {
+  static_assert(C == 32 || C == 64, "one wave: layers 1-2");
+  constexpr int NT = 64, NV = 1024 / NT;
+  constexpr int VEC = 16 / sizeof(WT), G = 1024 / C, R = C / 16;
+  constexpr int CG = C / VEC, KG = 1024 / CG, NIT = (9 * C + KG - 1) / KG;
+  constexpr int NROW = NV * NIT;                     // weight rows of this lane, virtual-thread-major: bf16 32 (C = 32) / 80 (C = 64)
+  constexpr int CHK = NROW % 20 == 0 ? 20 : 16;      // loads in flight: five waves on four SIMDs leave a wave 256 registers, and phase 1 holds 144 of them
+  static_assert(NROW % CHK == 0, "weight chunks");
+  const unsigned char* wbase = reinterpret_cast<const unsigned char*>(a.w2t);
+  auto wrow = [&](int r) {                           // row r = (virtual thread j, trip i): k = kg + i KG, 16 B of output channels
+    const int j = r / NIT, i = r % NIT;
+    const int v = lane + j * NT, cg = v % CG, k = v / CG + i * KG;
+    const unsigned off = (unsigned)k * (unsigned)(C * sizeof(WT)) + (unsigned)cg * 16u;
+    const uint4 val = *reinterpret_cast<const uint4*>(wbase + (k < 9 * C ? off : 0u));
+    return k < 9 * C ? val : make_uint4(0, 0, 0, 0);
+  };
+  uint4 w[CHK];
+#pragma unroll
+  for (int u = 0; u < CHK; ++u) w[u] = wrow(u);       // the first chunk travels while the sums are reduced
+  const int hb = halve(a.lens.get_uniform(b), a.halvings);
+  const int nt = (hb + a.th - 1) / a.th;
+#pragma unroll
+  for (int jh = 0; jh < NV; jh += NV / 2) {           // the virtual threads in two halves: 8 x 9 registers of sums and operands at a time
+    constexpr int NH = NV / 2;
+    float T[NH], C0[NH], CL[NH];
+#pragma unroll
+    for (int j = 0; j < NH; ++j) T[j] = C0[j] = CL[j] = 0.f;
+    for (int t0 = 0; t0 < nt; t0 += G) {
+      float vT[NH][4], vC0[NH], vCL[NH];
+#pragma unroll
+      for (int j = 0; j < NH; ++j) {
+        const int v = lane + (jh + j) * NT, c = v % C, t = t0 + v / C;
+        const bool ok = t < nt;
+        const size_t tt = (size_t)b * a.tiles + (ok ? t : 0);
+#pragma unroll
+        for (int wv = 0; wv < 4; ++wv) vT[j][wv] = (ok && wv < a.wm) ? a.se_part[(tt * a.wm + (wv < a.wm ? wv : 0)) * C + c] : 0.f;
+        vC0[j] = ok ? a.col_part[tt * 2 * C + c] : 0.f;
+        vCL[j] = ok ? a.col_part[tt * 2 * C + C + c] : 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < NH; ++j) {
+#pragma unroll
+        for (int wv = 0; wv < 4; ++wv) T[j] += vT[j][wv];
+        C0[j] += vC0[j];
+        CL[j] += vCL[j];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NH; ++j) { const int v = lane + (jh + j) * NT; red[v] = T[j]; red[1024 + v] = C0[j]; red[2048 + v] = CL[j]; }
+  }
+  se_wave_sync();
+  for (int c = lane; c < C; c += NT) {
+    float T = 0.f, C0 = 0.f, CL = 0.f;
+    for (int q = 0; q < G; ++q) { T += red[q * C + c]; C0 += red[1024 + q * C + c]; CL += red[2048 + q * C + c]; }
+    const float* eg = a.edge + (size_t)b * 6 * C + c;
+    const float R0 = eg[0], RL = eg[C], k00 = eg[2 * C], k0L = eg[3 * C], kL0 = eg[4 * C], kLL = eg[5 * C];
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const float rex = kh == 0 ? RL : (kh == 2 ? R0 : 0.f);
+        const float cex = kw == 0 ? CL : (kw == 2 ? C0 : 0.f);
+        const float corner = (kh == 0 && kw == 0) ? kLL : (kh == 0 && kw == 2) ? kL0 : (kh == 2 && kw == 0) ? k0L : (kh == 2 && kw == 2) ? k00 : 0.f;
+        S[(kh * 3 + kw) * C + c] = T - rex - cex + corner;
+      }
+  }
+  se_wave_sync();
+  {  // phase 2, fully unrolled: rows in (virtual thread, trip) order, chunks of CHK loads; one accumulator set live at a time
+    float m[VEC];
+#pragma unroll
+    for (int r0 = 0; r0 < NROW; r0 += CHK) {
+#pragma unroll
+      for (int u = 0; u < CHK; ++u) {
+        const int r = r0 + u, j = r / NIT, i = r % NIT;
+        const int v = lane + j * NT, cg = v % CG, kg = v / CG, k = kg + i * KG;
+        if (i == 0) {
+#pragma unroll
+          for (int q = 0; q < VEC; ++q) m[q] = 0.f;
+        }
+        if (k < 9 * C) {
+          const float s = S[k];
+          const uint32_t ww[4] = {w[u].x, w[u].y, w[u].z, w[u].w};
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            if constexpr (sizeof(WT) == 2) {
+              m[2 * q] = fmaf(bf16_to_f32((uint16_t)(ww[q] & 0xffff)), s, m[2 * q]);
+              m[2 * q + 1] = fmaf(bf16_to_f32((uint16_t)(ww[q] >> 16)), s, m[2 * q + 1]);
+            } else {
+              m[q] = fmaf(__builtin_bit_cast(float, ww[q]), s, m[q]);
+            }
+          }
+        }
+        if (i == NIT - 1) {
+#pragma unroll
+          for (int q = 0; q < VEC; ++q) red[kg * C + cg * VEC + q] = m[q];
+        }
+        if (r + CHK < NROW) w[u] = wrow(r + CHK);     // the slot is free: the next chunk's row
+      }
+    }
+  }
+  se_wave_sync();
+  {
+    float part[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int v = lane + j * NT, c = v % C, g = v / C;
+      float t = 0.f;
+      for (int q = g; q < KG; q += G) t += red[q * C + c];
+      part[j] = t;
+    }
+    se_wave_sync();
+#pragma unroll
+    for (int j = 0; j < NV; ++j) red[lane + j * NT] = part[j];
+    se_wave_sync();
+    for (int c = lane; c < C; c += NT) {
+      float t = 0.f;
+      for (int q = 0; q < G; ++q) t += red[q * C + c];
+      y[c] = t / (float)(hb * a.wout) * a.scale2[c] + a.shift2[c];
+    }
+  }
+  se_wave_sync();
+  constexpr int NF = C * R;
+  for (int idx = lane; idx < NF; idx += NT) { red[idx] = a.fc1[idx]; red[4096 + idx] = a.fc2[idx]; }
+  se_wave_sync();
+  {
+    constexpr int NS = C / 16;
+    for (int v = lane; v < R * NS; v += NT) {
+      const int r1 = v % R, sl = v / R;
+      float s = 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) s = fmaf(red[r1 * C + sl * 16 + k], y[sl * 16 + k], s);
+      S[sl * R + r1] = s;
+    }
+    se_wave_sync();
+    if (lane < R) {
+      float s = 0.f;
+      for (int q = 0; q < NS; ++q) s += S[q * R + lane];
+      hid[lane] = relu_nan(s);
+    }
+  }
+  se_wave_sync();
+  for (int c = lane; c < C; c += NT) {
+    float z = 0.f;
+    for (int k = 0; k < R; ++k) z = fmaf(red[4096 + c * R + k], hid[k], z);
+    gate_out[c] = 1.f / (1.f + expf(-z));
+  }
+  se_wave_sync();
+}
+
 constexpr int SE_GATE_SCRATCH_FLOATS = 8192 + 9 * 256 + 256 + 16;   // red, S, y, hid
 
 }  // namespace sk

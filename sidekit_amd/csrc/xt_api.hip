@@ -109,11 +109,15 @@ struct xt_handle {
   bool shortcut_tensor = getenv("SIDEKIT_AMD_SHORTCUT_TENSOR") != nullptr;   // A/B switch, see half_from_feats
   bool mel_gemm = getenv("SIDEKIT_AMD_MEL_GEMM") != nullptr;                 // A/B switch: mel projection as a separate GEMM
   bool mfcc_dft_gemm = getenv("SIDEKIT_AMD_MFCC_DFT_GEMM") != nullptr;       // A/B switch: MFCC spectrum as a DFT contraction (round-1 form) instead of the FFT
-  // SE gate in conv2's prologue instead of a launch of its own (se_gate_inl.h): 0 (default) never, 1 for small grids (at most 8 utterances), 2 always.
-  // Built and measured as the round-4 verdict specified it (separate instantiation, every workgroup of an utterance reduces the sums in
-  // se_pre_kernel's order: bit-identical, tests/test_gpu_halfresnet.py) -- and it does not pay: the gate is a chain of dependent L2 round trips
-  // and barriers that takes 5-6 us whether it runs as a kernel (5.7-7.3 us, floor of a dependent launch included) or at the head of conv2
-  // (+5.4-6.3 us per conv2, +23 us for layer 4): 0.690 vs 0.687 ms per 4-s utterance, profiles/r05_latency_matrix.txt.  Off; kept for A/B.
+  // SE gate computed inside conv2 instead of by a launch of its own (se_gate_inl.h).  Two forms were built in round 5; both give se_pre_kernel's
+  // bits (tests/test_gpu_halfresnet.py) and NEITHER pays (profiles/r05_latency_matrix.txt), so the default is 0 = the launch:
+  //  - prologue (3 = small grids, 4 = always; the round-4 verdict's specification: a separate instantiation in which every workgroup of an
+  //    utterance reduces the sums in se_pre_kernel's order before its k-loop): the gate is a chain of dependent L2 round trips and barriers
+  //    that takes 5-6 us whether it runs as a kernel (5.7-7.3 us) or at the head of conv2 (+5.4-6.3 us per conv2, +23 us for layer 4):
+  //    0.690 vs 0.687 ms per 4-s utterance on one box, 0.663 vs 0.618 on another;
+  //  - gate wave (1 = small grids, 2 = always; layers 1-2): a fifth wave computes the gate WHILE the four convolution waves stage the tile and
+  //    run the k-loop, joining their barriers.  Concurrent, no launch -- but ONE wave walks the chain in ~10 us where the 16-wave kernel
+  //    needs 1-2, longer than the convolution it hides behind: 0.636 vs 0.618 ms.
   int gate_prologue = getenv("SIDEKIT_AMD_GATE_PROLOGUE") ? atoi(getenv("SIDEKIT_AMD_GATE_PROLOGUE")) : 0;
   // small-grid tilings for conv2 of layers 3-4 (conv3x3.hip, "Small-grid forms"): 1 (default) at most 8 utterances, 0 never, 2 always
   int small_grid = getenv("SIDEKIT_AMD_SMALL_GRID") ? atoi(getenv("SIDEKIT_AMD_SMALL_GRID")) : 1;
@@ -776,7 +780,11 @@ static int half_from_feats(xt_handle* h, Lane& ln, const float* feats, long sb, 
     // chain of dependent launches, each as long as ONE wave's work: conv2 of layers 3-4 runs in 3- / 5-row tiles (more, shorter workgroups).  Same bits.
     const bool small = dt == DT_BF16 && (h->small_grid == 2 || (h->small_grid == 1 && B <= 8 && (long)B * Hl[li] <= 4096));
     const int c2shape = !small ? b.c2.shape : (li == 2 ? (int)CONV_L3T : (li == 3 ? (int)CONV_L4T : b.c2.shape));
-    const bool gate_pro = h->gate_prologue == 2 || (h->gate_prologue == 1 && B <= 8 && (long)B * Hl[li] <= 4096);
+    // 1 (default): small grids, layers 1-2 -- conv2's fifth wave computes the gate beside the k-loop; 2: the same at any batch size (tests);
+    // 3 / 4: the prologue form (every workgroup computes the gate before its k-loop; measured, no gain), small grids / always
+    const bool small_b = B <= 8 && (long)B * Hl[li] <= 4096;
+    const int gate_pro = (h->gate_prologue == 2 || (h->gate_prologue == 1 && small_b)) ? (b.C <= 64 ? 2 : 0)
+                         : ((h->gate_prologue == 4 || (h->gate_prologue == 3 && small_b)) ? 1 : 0);
     if (!gate_pro) {
       ProfScope ps(h, XT_PROF_SE_RES, st);
       SK_TRY(launch_se_pre(se, st));
@@ -785,12 +793,12 @@ static int half_from_feats(xt_handle* h, Lane& ln, const float* feats, long sb, 
     a.in = O1; a.wpack = b.c2.wpack; a.scale = b.c2.scale; a.shift = b.c2.shift; a.out = O2;
     a.se_part = nullptr; a.col_part = nullptr; a.edge = nullptr; a.gate = (const float*)ln.ws_gate.p; a.shortcut = shortcut;
     a.halvings_in = li; a.Hin = Hl[li]; a.Hout = Hl[li]; a.relu = 0;
-    if (gate_pro) { a.gate_pro = 1; a.se = se; }     // every workgroup of conv2 derives its utterance's gate itself; ws_gate is not read
+    if (gate_pro) { a.gate_pro = gate_pro; a.se = se; }     // every workgroup of conv2 derives its utterance's gate itself; ws_gate is not read
     if (inplace_sc) {
       a.shortcut = nullptr; a.sc_in = X; a.sc_hin = Hl[lin];
       a.sc_wpack = b.sc_wfold; a.sc_scale = b.sc.scale; a.sc_shift = b.sc.shift;
     }
-    { ProfScope ps(h, b.c2.shape, st); SK_TRY(launch_conv(c2shape, dt, a, st)); }
+    { ProfScope ps(h, b.c2.shape, st); SK_TRY(launch_conv((gate_pro == 2 && li == 0 && dt == DT_BF16) ? (int)CONV_L1G : c2shape, dt, a, st)); }
     std::swap(X, O2);
     const bool last_of_layer = (bi + 1 == h->blocks.size()) || (h->blocks[bi + 1].li != li);
     if (last_of_layer) {

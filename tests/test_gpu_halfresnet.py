@@ -299,17 +299,17 @@ def test_embedding_does_not_depend_on_the_batch_size(gpu):
 
 
 def test_small_grid_forms_give_the_bits_of_the_batch_forms(gpu, monkeypatch):
-    """Small batches (<= 8 utterances: the reference driver's call shape, sidekit/bin/extract_xvectors.py:146) run layers 2-4 on their small-grid
-    convolution shapes (deep weight rings, conv2 of layers 3-4 in 3- / 5-row tiles: csrc/conv3x3.hip) and may take their SE gates from conv2's
-    prologue (csrc/se_gate_inl.h: every workgroup of an utterance walks the 1024 virtual threads of ``se_pre_kernel`` on its 256 real ones)
-    instead of the launch of ``se_pre_kernel`` between conv1 and conv2 (sidekit/nnet/res_net.py:272-281,316-319).  Forced either way on
-    models with the same weights (SIDEKIT_AMD_SMALL_GRID / _GATE_PROLOGUE = 0 / 2), x-vectors and logits are the same bits at every batch
-    size -- batch 1 at 4 s and 45 s (563 row tiles: persistent workgroups walk several tiles of the utterance), ragged batches, a batch of 40
-    -- in both precisions; and the automatic choice agrees with both."""
+    """Small batches (<= 8 utterances: the reference driver's call shape, sidekit/bin/extract_xvectors.py:146) run conv2 of layers 3-4 in 3- / 2-row
+    tiles (csrc/conv3x3.hip, "Small-grid forms").  Two ways of computing the SE gate INSIDE conv2 instead of by the launch of ``se_pre_kernel``
+    between conv1 and conv2 (sidekit/nnet/res_net.py:272-281,316-319) exist beside that (csrc/se_gate_inl.h; measured, off by default): a
+    fifth wave of conv2 (layers 1-2) and a prologue in which every workgroup of an utterance walks the 1024 virtual threads of
+    ``se_pre_kernel`` on its 256 real ones (every layer).  Forced on / off on models with the same weights (SIDEKIT_AMD_SMALL_GRID,
+    SIDEKIT_AMD_GATE_PROLOGUE), x-vectors and logits are the same bits at every batch size -- batch 1 at 4 s and 45 s (563 row tiles), ragged
+    batches, a batch of 40 -- in both precisions; and the automatic choice agrees with all of them."""
     models = {}
-    for mode in ("0", "2", "1"):
-        monkeypatch.setenv("SIDEKIT_AMD_GATE_PROLOGUE", mode)
-        monkeypatch.setenv("SIDEKIT_AMD_SMALL_GRID", mode)
+    for mode, gate in (("0", "0"), ("2", "2"), ("1", "1"), ("4", "4")):    # gate: 2 = the fifth-wave form (layers 1-2) always, 4 = the prologue form (every layer) always
+        monkeypatch.setenv("SIDEKIT_AMD_GATE_PROLOGUE", gate)
+        monkeypatch.setenv("SIDEKIT_AMD_SMALL_GRID", "1" if mode == "4" else mode)
         m = Xtractor(64, model_archi="halfresnet34", loss="aam", seed=41).to(gpu).eval()
         m.compute_dtype = "fp32"; m(torch.zeros(1, 4000, device="cuda") + 0.01, is_eval=True)      # the handles are created under this setting
         m.compute_dtype = "bf16"; m(torch.zeros(1, 4000, device="cuda") + 0.01, is_eval=True)
@@ -324,7 +324,7 @@ def test_small_grid_forms_give_the_bits_of_the_batch_forms(gpu, monkeypatch):
             for mode, m in models.items():
                 m.compute_dtype = dt
                 outs[mode] = m(wav, is_eval=True, lengths=lens)
-            for mode in ("2", "1"):
+            for mode in ("2", "1", "4"):
                 assert torch.equal(outs[mode][1], outs["0"][1]) and torch.equal(outs[mode][0], outs["0"][0]), (B, L, ragged, dt, mode)
     torch.cuda.synchronize()
 
