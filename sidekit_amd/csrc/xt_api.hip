@@ -119,7 +119,7 @@ struct xt_handle {
   //    run the k-loop, joining their barriers.  Concurrent, no launch -- but ONE wave walks the chain in ~10 us where the 16-wave kernel
   //    needs 1-2, longer than the convolution it hides behind: 0.636 vs 0.618 ms.
   int gate_prologue = getenv("SIDEKIT_AMD_GATE_PROLOGUE") ? atoi(getenv("SIDEKIT_AMD_GATE_PROLOGUE")) : 0;
-  // small-grid tilings for conv2 of layers 3-4 (conv3x3.hip, "Small-grid forms"): 1 (default) at most 8 utterances, 0 never, 2 always
+  // small-grid tilings for conv2 of layers 3-4 (conv3x3.hip, "Small-grid forms"): 1 (default) at most 12 utterances, 0 never, 2 always
   int small_grid = getenv("SIDEKIT_AMD_SMALL_GRID") ? atoi(getenv("SIDEKIT_AMD_SMALL_GRID")) : 1;
   xt_config cfg;
   int device = 0;
@@ -776,9 +776,9 @@ static int half_from_feats(xt_handle* h, Lane& ln, const float* feats, long sb, 
       a.se_part = nullptr; a.col_part = nullptr; a.edge = nullptr; a.relu = 0;
       { ProfScope ps(h, b.sc.shape, st); SK_TRY(launch_conv(b.sc.shape, dt, a, st)); }
     }
-    // small grids (at most 8 utterances: the reference driver's one-utterance-at-a-time call shape, sidekit/bin/extract_xvectors.py:146): a forward is a
+    // small grids (at most 12 utterances; 1 is the reference driver's call shape, sidekit/bin/extract_xvectors.py:146): a forward is a
     // chain of dependent launches, each as long as ONE wave's work: conv2 of layers 3-4 runs in 3- / 5-row tiles (more, shorter workgroups).  Same bits.
-    const bool small = dt == DT_BF16 && (h->small_grid == 2 || (h->small_grid == 1 && B <= 8 && (long)B * Hl[li] <= 4096));
+    const bool small = dt == DT_BF16 && (h->small_grid == 2 || (h->small_grid == 1 && B <= 12 && (long)B * Hl[li] <= 4096));   // crossover between 12 and 16 utterances (profiles/r05_small_grid_sweep.txt)
     const int c2shape = !small ? b.c2.shape : (li == 2 ? (int)CONV_L3T : (li == 3 ? (int)CONV_L4T : b.c2.shape));
     // 1 (default): small grids, layers 1-2 -- conv2's fifth wave computes the gate beside the k-loop; 2: the same at any batch size (tests);
     // 3 / 4: the prologue form (every workgroup computes the gate before its k-loop; measured, no gain), small grids / always
