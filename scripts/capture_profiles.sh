@@ -6,7 +6,7 @@
 # (--pipeline 1 --lanes 1): in the two-lane product configuration kernels of the two half batches overlap and one kernel's duration or counter
 # says nothing about that kernel; one extra trace of the two-lane run is kept for the record.
 set -e -o pipefail
-TAG=${1:-r03}
+TAG=${1:-r05}
 OUT=gpurun_out
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
