@@ -192,3 +192,31 @@ def test_config5_oracle_matches_reference_at_full_size(golden_dir):
             numpy.testing.assert_allclose(pm, fx["plda_pmiss"], atol=1e-12)
             numpy.testing.assert_allclose(pf, fx["plda_pfa"], atol=1e-12)
         assert abs(osc.rocch2eer(pm, pf) - float(fx[f"{tag}_eer"])) < 1e-6
+
+
+def test_frontend_restatement_against_independent_implementations():
+    """The mel / MFCC arithmetic lives in un-vendored torchaudio 0.8.2 (sidekit/nnet/preprocessor.py:104-109,253-261; install.sh:36) and
+    nothing in the reference tree pins it: **parity unpinned**, and this test does not change that.  What it adds is a second witness that
+    is not this repository's own reading: the image holds HuggingFace ``transformers.audio_utils`` -- a numpy implementation "adapted from
+    torchaudio and librosa" -- and scipy.  The oracle's HTK filter banks (both front-ends' parameters), its power spectrogram (periodic Hann
+    window centred in the FFT frame, reflect padding, one-sided, power 2) and its orthonormal DCT-II agree with them to float32 / float64
+    round-off."""
+    au = pytest.importorskip("transformers.audio_utils")
+    import scipy.fft
+    from oracle import frontend as ofe
+    for n_fft, n_mels, f_min, f_max in ((1024, 80, 90.0, 7600.0), (2048, 100, 133.333, 6855.4976)):       # preprocessor.py:216-226, :65-76
+        mine = ofe.mel_filterbank(n_fft // 2 + 1, f_min, f_max, n_mels, 16000).numpy().astype(numpy.float64)
+        theirs = au.mel_filter_bank(n_fft // 2 + 1, n_mels, f_min, f_max, 16000, norm=None, mel_scale="htk")
+        assert mine.shape == theirs.shape and numpy.abs(mine - theirs).max() < 2e-5          # the oracle forms it in float32 like torchaudio
+        assert (mine > 0).sum(axis=0).min() >= 1                                             # no empty filter at these parameters
+    x = 0.1 * torch.randn(1, 16000, generator=torch.Generator().manual_seed(0))
+    for n_fft, win, hop in ((1024, 400, 160), (2048, 1024, 512)):
+        mine = ofe.stft_power(x.double(), n_fft, hop, win, window=ofe.hann_window(win, torch.float64))[0].numpy()
+        w = au.window_function(win, "hann", periodic=True, frame_length=n_fft, center=True)
+        theirs = au.spectrogram(x[0].numpy().astype(numpy.float64), w, frame_length=n_fft, hop_length=hop, fft_length=n_fft, power=2.0, center=True,
+                                pad_mode="reflect", onesided=True, dtype=numpy.float64)
+        assert mine.shape == theirs.shape == (n_fft // 2 + 1, 1 + 16000 // hop)
+        assert numpy.abs(mine - theirs).max() < 1e-6 * numpy.abs(theirs).max()
+    dct = ofe.dct_matrix(80, 100).numpy().astype(numpy.float64)                               # (n_mels, n_mfcc): MFCC = log-mel @ dct
+    ref = scipy.fft.dct(numpy.eye(100), type=2, norm="ortho", axis=0)[:80].T                  # DCT-II, orthonormal
+    assert numpy.abs(dct - ref).max() < 1e-5                                                  # float32 cosines of arguments up to 250, as torchaudio forms them
