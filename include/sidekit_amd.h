@@ -90,7 +90,7 @@ int xt_forward_pcm16(xt_handle* h, const int16_t* d_pcm, int64_t pcm_ld, const i
 
 /* Pipelined forwards: two WHOLE batches in flight instead of the two halves of one.  The reference driver's loop
  * (sidekit/bin/extract_xvectors.py:130-150) is one forward at a time; a corpus is many independent batches, and two of them half a step
- * apart use the chip better than one alone (one batch's HBM-bound first layer beside the other's MFMA-bound deep layers: 5.61 vs 5.78 ms
+ * apart use the chip better than one alone (one batch's HBM-bound first layer beside the other's MFMA-bound deep layers: 5.67 vs 5.87 ms
  * per batch of 256 on MI355X).  xt_reserve_slots sizes `slots` (<= 4; 2 is what pays) full workspaces, each with a stream the handle
  * owns.  xt_forward_begin queues the whole forward of a batch on slot `slot`'s stream -- behind everything queued on `stream` so far --
  * and returns without joining; in_dtype XT_F32 (d_wav float32) or XT_I16 (16-bit PCM as in xt_forward_pcm16).  xt_forward_end makes

@@ -1226,7 +1226,7 @@ int xt_forward_pcm16(xt_handle* h, const int16_t* d_pcm, int64_t pcm_ld, const i
 }
 
 // ---- pipelined forwards (round 4) -----------------------------------------------------------------------------------------------
-// Two WHOLE batches in flight on two streams the handle owns beat two half batches side by side (5.61 vs 5.78 ms per batch of 256,
+// Two WHOLE batches in flight on two streams the handle owns beat two half batches side by side (5.67 vs 5.87 ms per batch of 256 in one bench.py run, profiles/r05_bench_line.json; first measured by
 // scripts/alt_streams.py): consecutive forwards run half a step apart, so one batch's HBM-bound layer 1 overlaps the other's
 // MFMA-bound layers 3-4 -- and nothing joins at the end of a call.  A slot is a full-size workspace + a stream; xt_forward_begin queues
 // the whole (serial) forward of a batch on its slot's stream behind everything queued on the caller's stream so far and returns;

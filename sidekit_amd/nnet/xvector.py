@@ -170,7 +170,7 @@ class Xtractor:
 
         The reference driver runs one forward at a time (``extract_xvectors.py:130-150``); a corpus is many independent batches, and keeping
         ``pipeline_depth`` (2) of them in flight -- each on a stream the handle owns, half a step apart -- uses the chip better than the two
-        halves of one batch side by side (5.61 vs 5.78 ms per batch of 256).  Tickets must be collected in submission order; at most
+        halves of one batch side by side (5.67 vs 5.87 ms per batch of 256 in one run of bench.py, profiles/r05_bench_line.json).  Tickets must be collected in submission order; at most
         ``pipeline_depth`` may be outstanding.  The x-vectors are the bits ``forward`` returns."""
         x = self._check_input(x, pcm16_ok=True)
         B, L = x.shape
