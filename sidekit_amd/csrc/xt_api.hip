@@ -777,11 +777,11 @@ static int half_from_feats(xt_handle* h, Lane& ln, const float* feats, long sb, 
       { ProfScope ps(h, b.sc.shape, st); SK_TRY(launch_conv(b.sc.shape, dt, a, st)); }
     }
     // small grids (at most 12 utterances; 1 is the reference driver's call shape, sidekit/bin/extract_xvectors.py:146): a forward is a
-    // chain of dependent launches, each as long as ONE wave's work: conv2 of layers 3-4 runs in 3- / 5-row tiles (more, shorter workgroups).  Same bits.
+    // chain of dependent launches, each as long as ONE wave's work: conv2 of layers 3-4 runs in 3- / 2-row tiles (more, shorter workgroups).  Same bits.
     const bool small = dt == DT_BF16 && (h->small_grid == 2 || (h->small_grid == 1 && B <= 12 && (long)B * Hl[li] <= 4096));   // crossover between 12 and 16 utterances (profiles/r05_small_grid_sweep.txt)
     const int c2shape = !small ? b.c2.shape : (li == 2 ? (int)CONV_L3T : (li == 3 ? (int)CONV_L4T : b.c2.shape));
-    // 1 (default): small grids, layers 1-2 -- conv2's fifth wave computes the gate beside the k-loop; 2: the same at any batch size (tests);
-    // 3 / 4: the prologue form (every workgroup computes the gate before its k-loop; measured, no gain), small grids / always
+    // the gate inside conv2 (A/B forms, off by default: see xt_handle::gate_prologue).  1 / 2: layers 1-2, conv2's fifth wave computes it beside the k-loop
+    // (small grids / always); 3 / 4: every layer, every workgroup computes it before its k-loop (small grids / always)
     const bool small_b = B <= 8 && (long)B * Hl[li] <= 4096;
     const int gate_pro = (h->gate_prologue == 2 || (h->gate_prologue == 1 && small_b)) ? (b.C <= 64 ? 2 : 0)
                          : ((h->gate_prologue == 4 || (h->gate_prologue == 3 && small_b)) ? 1 : 0);
