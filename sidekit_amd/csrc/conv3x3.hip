@@ -581,8 +581,8 @@ void conv3x3_kernel(ConvArgs a) {
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int t = 0; t < HT; ++t)
-#pragma unroll
+        for (int t = 0; t < HT; ++t)      // (round 5: the other order -- one weight fragment held over HT consecutive MFMAs -- is no cheaper for the power-limited
+#pragma unroll                            //  chip: layers 3 / 4 1.406 / 0.693 vs 1.397 / 0.681 ms per step, profiles/r05_ab_mfma_issue_order.txt)
           for (int jn = 0; jn < C::NT16; ++jn) {
             if (t0 + t >= C::PT16) continue;   // S2G: five tiles in six slots
             // accumulator of (position tile t, channel tile jn) = quarter 2 * (t & 1) + (jn & 1) of acc[t / 2][jn / 2]
