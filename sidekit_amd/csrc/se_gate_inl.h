@@ -2,13 +2,16 @@
 // the same sums in the same order, so the gate is the same bits whichever kernel produced it.
 //
 // Why it exists (round 5): the reference driver calls the model one utterance at a time (sidekit/bin/extract_xvectors.py:130-150); at batch 1
-// a forward is a chain of 60 dependent kernels of which sixteen are SE gates -- 5.7-7.3 us each for layers 1-3 (the floor of a dependent
-// launch) and 16 us for layer 4, 135 us of a 0.67-ms forward (profiles/r05_b1_kernel_stats_before.csv).  The gate is needed only by conv2's
-// EPILOGUE, and the kernel boundary between conv1 and conv2 already makes conv1's sums visible.  So for small batches conv2 itself -- a
-// separate template instantiation, the batch-256 kernels keep their registers -- lets every workgroup of an utterance compute that
-// utterance's gate while its halo tile is landing in LDS: no launch, no fences, no tickets (the round-4 construction, conv1's last workgroup
-// behind agent-scope releases, lost for exactly those).  The work is redundant across the utterance's workgroups (9 C^2 MACs and as many
-// weight bytes from L2 each), which is why it is selected for small grids only (launch_cfg in conv3x3.hip).
+// a forward is a chain of 60 dependent kernels of which sixteen are SE gates -- 5.7-7.3 us each for layers 1-3 and 16 us for layer 4, 135 us
+// of a 0.67-ms forward (profiles/r05_b1_kernel_stats_before.csv).  The gate is needed only by conv2's EPILOGUE, and the kernel boundary between
+// conv1 and conv2 already makes conv1's sums visible.  The round-4 verdict asked for the gate in conv2's prologue -- a separate template
+// instantiation (the batch-256 kernels keep their registers) in which every workgroup of an utterance computes that utterance's gate itself:
+// no launch, no fences, no tickets (round 4's construction, conv1's last workgroup behind agent-scope releases, lost for exactly those).
+// Built, bit-identical, and MEASURED: it does not pay either.  The gate is a chain of dependent L2 round trips (conv1's sums come from other
+// XCDs' write-backs; 9 C^2 weight bytes pass one CU's L2 port) and barriers that takes 5-6 us whether it is a kernel or the head of one; on one
+// wave beside the k-loop (se_gate_wave below) it takes ~10 us, longer than the convolution it would hide behind (xt_api.hip, xt_handle::
+// gate_prologue; profiles/r05_latency_matrix.txt).  The forms stay selectable for A/B and are tested for bit-identity; the product launches
+// se_pre_kernel.
 //
 // se_pre_kernel runs 1024 threads; here NT (256) threads each walk 1024 / NT "virtual threads" v = tid + j NT of that kernel.  Every
 // reduction keeps se_pre_kernel's partition (which virtual thread owns which partial sum) and its order (partials are combined in index
