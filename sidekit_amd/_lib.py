@@ -13,10 +13,17 @@ if os.environ.get("SIDEKIT_AMD_LIB"):   # tuning aid: another build of the SAME 
     LIB_PATH = os.path.abspath(os.environ["SIDEKIT_AMD_LIB"])
     import warnings
     warnings.warn(f"SIDEKIT_AMD_LIB is set: loading {LIB_PATH} instead of the shipped csrc/libsidekit_amd.so (A/B tuning aid)", RuntimeWarning)
-for _tuning in ("SIDEKIT_AMD_SHAPE_MAP", "SIDEKIT_AMD_CONV_DBG"):
-    if os.environ.get(_tuning):
-        import warnings
-        warnings.warn(f"{_tuning}={os.environ[_tuning]!r} is set: kernels differ from the product configuration (A/B tuning aid)", RuntimeWarning)
+# The product library reads SIDEKIT_AMD_LANES and SIDEKIT_AMD_SMALL_GRID (csrc/common.h); every other SIDEKIT_AMD_* switch exists only in the A/B
+# build (csrc/Makefile `make ab` -> libsidekit_amd_ab.so, loaded through SIDEKIT_AMD_LIB).  Say so instead of silently ignoring or obeying one.
+_PRODUCT_VARS = {"SIDEKIT_AMD_LIB", "SIDEKIT_AMD_LANES", "SIDEKIT_AMD_SMALL_GRID", "SIDEKIT_AMD_PIPELINE_DEPTH"}
+_IS_AB_BUILD = os.path.basename(LIB_PATH) != "libsidekit_amd.so"
+for _tuning in sorted(k for k in os.environ if k.startswith("SIDEKIT_AMD_") and k not in _PRODUCT_VARS):
+    import warnings
+    if _IS_AB_BUILD:
+        warnings.warn(f"{_tuning}={os.environ[_tuning]!r} is set: kernels may differ from the product configuration (A/B tuning aid)", RuntimeWarning)
+    else:
+        warnings.warn(f"{_tuning} is set but the product library ignores it: A/B switches exist only in libsidekit_amd_ab.so "
+                      f"(make -C sidekit_amd/csrc ab; SIDEKIT_AMD_LIB=<that file>)", RuntimeWarning)
 
 SK_OK, SK_EARG, SK_ESHAPE, SK_EHIP, SK_EWORKSPACE, SK_ESTATE = 0, -1, -2, -3, -4, -5
 XT_ARCH_HALFRESNET34, XT_ARCH_TDNN = 0, 1

@@ -75,6 +75,15 @@ def plda_moments(X, labels, rank):
     return mu, F, Sigma
 
 
+def hist_range_from_sample(scoring, xv, dev):
+    """[lo, hi) of the all-pairs histograms from a strided sample of 2048 x-vectors: the smallest sampled score, widened by a quarter of the
+    sampled range (never below -1), up to 1."""
+    N = xv.shape[0]
+    sample = xv[:: max(1, N // 2048)][:2048]
+    smin = float(scoring.cosine_matrix_device(sample, sample, dev).min())
+    return max(-1.0, smin - 0.25 * (1.0 - smin)), 1.0 + 1e-6
+
+
 def load_plda(path):
     """(mu, F, Sigma) float64 from a SIDEKIT PLDA HDF5 file (sidekit_io.py:282-324) or an .npz holding those three arrays."""
     if path.endswith(".npz"):
@@ -96,6 +105,11 @@ def main(argv=None, model=None, scoring=None, keep=None):
     ap.add_argument("--noise", type=float, default=0.004, help="white-noise level of the synthetic utterances (sets the EER: 0.004 -> cosine ~15 %, PLDA ~10 %; 0.03 -> 46 %)")
     ap.add_argument("--plda-rank", type=int, default=128)
     ap.add_argument("--all-pairs", action="store_true", help="also score every pair of the corpus into histograms (no N x N matrix)")
+    ap.add_argument("--hist-range", type=float, nargs=2, default=None, metavar=("LO", "HI"),
+                    help="score range of the all-pairs histograms; default: derived from a sample of THIS run's x-vectors.  Two runs that are to be "
+                         "compared (fp32 against bf16, tests/test_gpu_eer_dtype.py) must be binned on the same edges: pass the first run's range to the second")
+    ap.add_argument("--hist-bins", type=int, default=None, help="bins of the all-pairs histograms: 8192 (default, one pass) or a multiple of 8190 (that many passes / 8190)")
+    ap.add_argument("--seed", type=int, default=0, help="corpus seed: another draw of speaker labels, phases, amplitude jitter and noise for the same speaker table")
     ap.add_argument("--plda", default=None, help="PLDA (mu, F, Sigma): SIDEKIT HDF5 or .npz; default: moment estimate from the corpus")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="nccl = RCCL over xGMI; gloo for CPU rehearsals")
     ap.add_argument("--device", default="cuda", choices=["cuda", "cpu"], help="cpu only with an injected model / scoring module")
@@ -122,7 +136,7 @@ def main(argv=None, model=None, scoring=None, keep=None):
         model.compute_dtype = args.dtype
     L = int(args.seconds * 16000)
     N = args.utterances
-    labels = numpy.random.RandomState(1).randint(0, args.speakers, N).astype(numpy.int32)     # speaker of every utterance
+    labels = numpy.random.RandomState(1 + args.seed).randint(0, args.speakers, N).astype(numpy.int32)     # speaker of every utterance
     freqs, amps = speaker_table(args.speakers)
     start, stop = shard_range(N, rank, world)
     n_batches = (stop - start + args.batch - 1) // args.batch
@@ -133,7 +147,7 @@ def main(argv=None, model=None, scoring=None, keep=None):
     for k in range(n_batches):
         lo = start + k * args.batch
         hi = min(lo + args.batch, stop)
-        g = torch.Generator(device=dev).manual_seed(1000 + lo)        # a batch's seed = its first utterance: independent of the rank count when shards are batch aligned
+        g = torch.Generator(device=dev).manual_seed(1000 + lo + 1000003 * args.seed)   # a batch's seed = its first utterance: independent of the rank count when shards are batch aligned
         wav = synth_batch(labels[lo:hi], freqs, amps, L, args.noise, g, dev)
         if pipelined:
             tickets.append(model.submit(wav))
@@ -187,12 +201,13 @@ def main(argv=None, model=None, scoring=None, keep=None):
         # histogram range from a strided sample of the gathered x-vectors (the same on every rank, no collective): 8192 bins over
         # [-1, 1) are 2.4e-4 wide, and an extractor whose x-vectors share a common direction (every score in [0.98, 1]) would land in a few
         # dozen of them -- the binned EER then carries the bin width, not the scores.  The bins go where the scores are (widened by a quarter
-        # of the sampled range; whatever falls outside is counted in the end bins by the kernel).
-        sample = xv[:: max(1, N // 2048)][:2048]
-        smin = float(scoring.cosine_matrix_device(sample, sample, dev).min())
-        lo = max(-1.0, smin - 0.25 * (1.0 - smin))
-        ht, hn = scoring.cosine_histograms(xv[a:b], xv, lab_d[a:b], lab_d, self_offset=a, lo=lo, hi=1.0 + 1e-6, device=dev)
-        out["all_pairs_hist_range"] = [lo, 1.0]
+        # of the sampled range; whatever falls outside is counted in the end bins by the kernel).  The range depends on the run's own
+        # x-vectors: two runs whose EERs are to be COMPARED must share it (--hist-range; round 5 compared fp32 and bf16 on different edges).
+        lo, hi = args.hist_range if args.hist_range else hist_range_from_sample(scoring, xv, dev)
+        ht, hn = scoring.cosine_histograms(xv[a:b], xv, lab_d[a:b], lab_d, self_offset=a, lo=lo, hi=hi, device=dev,
+                                           **({"bins": args.hist_bins} if args.hist_bins else {}))
+        out["all_pairs_hist_range"] = [lo, hi]
+        out["all_pairs_hist_bins"] = int(ht.shape[0])
         sync()
         counts = torch.as_tensor(numpy.stack([ht, hn]).astype(numpy.int64), device=dev)
         if dist.is_initialized():

@@ -8,6 +8,19 @@
 #include <string>
 
 #include "../../include/sidekit_amd.h"
+#include <stdlib.h>
+
+// A/B tuning switches.  The product library reads exactly two environment variables (SIDEKIT_AMD_LANES, SIDEKIT_AMD_SMALL_GRID); every other
+// SIDEKIT_AMD_* switch, the alternative convolution shapes of sk_bench_conv and the in-convolution SE-gate forms (se_gate_inl.h) exist only in the
+// A/B build of the same sources (`make ab` -> libsidekit_amd_ab.so, -DSK_AB), which the tests that compare a product path with its A/B partner load
+// in a child process (tests/test_gpu_01_ab_variant.py).
+#ifdef SK_AB
+#define SK_AB_GETENV(name) getenv(name)
+#define SK_AB_ENV_INT(name, dflt) (getenv(name) ? atoi(getenv(name)) : (dflt))
+#else
+#define SK_AB_GETENV(name) ((const char*)nullptr)
+#define SK_AB_ENV_INT(name, dflt) (dflt)
+#endif
 
 namespace sk {
 

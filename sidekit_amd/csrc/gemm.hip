@@ -428,7 +428,7 @@ int launch_gemm(const GemmArgs& g_in, hipStream_t s) {
   GemmArgs g = g_in;
   if (g.l2_done) *g.l2_done = 0;
   g.ksplit = 1; g.kslices = 1;
-  { const char* e = getenv("SIDEKIT_AMD_GEMM_DBG"); g.dbg = e ? atoi(e) : 0; }
+  g.dbg = SK_AB_ENV_INT("SIDEKIT_AMD_GEMM_DBG", 0);
   if (g.splitk_ws && g.K >= 1024) {   // the summation order depends on K alone; M only decides where the slices run
     const int nk = (g.K + BK - 1) / BK;
     g.kslices = nk / 8 < 32 ? (nk / 8 > 1 ? nk / 8 : 1) : 32;   // >= 8 k-tiles per slice, at most 32 slices
@@ -444,7 +444,7 @@ int launch_gemm(const GemmArgs& g_in, hipStream_t s) {
     SK_HIP(hipGetLastError());
     return SK_OK;
   }
-  if (g.ksplit == 1 && g.M >= 2048 && g.N >= 128 && g.a_mode == A_PLAIN && !g.a_bf16 && !getenv("SIDEKIT_AMD_GEMM64")) {   // large problem: 128 x 128 tiles (same numbers)
+  if (g.ksplit == 1 && g.M >= 2048 && g.N >= 128 && g.a_mode == A_PLAIN && !g.a_bf16 && !SK_AB_GETENV("SIDEKIT_AMD_GEMM64")) {   // large problem: 128 x 128 tiles (same numbers)
     dim3 grid2(cdiv(g.M, BM2), cdiv(g.N, BN2));
     if (g.kslices > 1) hipLaunchKernelGGL(gemm128_kernel<true>, grid2, dim3(256), 0, s, g);
     else hipLaunchKernelGGL(gemm128_kernel<false>, grid2, dim3(256), 0, s, g);

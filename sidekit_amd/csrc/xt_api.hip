@@ -106,9 +106,9 @@ static int lane_parts(int lanes, int B, int lane_min) {
 using namespace sk;
 
 struct xt_handle {
-  bool shortcut_tensor = getenv("SIDEKIT_AMD_SHORTCUT_TENSOR") != nullptr;   // A/B switch, see half_from_feats
-  bool mel_gemm = getenv("SIDEKIT_AMD_MEL_GEMM") != nullptr;                 // A/B switch: mel projection as a separate GEMM
-  bool mfcc_dft_gemm = getenv("SIDEKIT_AMD_MFCC_DFT_GEMM") != nullptr;       // A/B switch: MFCC spectrum as a DFT contraction (round-1 form) instead of the FFT
+  bool shortcut_tensor = SK_AB_GETENV("SIDEKIT_AMD_SHORTCUT_TENSOR") != nullptr;   // A/B builds only (common.h), see half_from_feats
+  bool mel_gemm = SK_AB_GETENV("SIDEKIT_AMD_MEL_GEMM") != nullptr;                 // A/B switch: mel projection as a separate GEMM
+  bool mfcc_dft_gemm = SK_AB_GETENV("SIDEKIT_AMD_MFCC_DFT_GEMM") != nullptr;       // A/B switch: MFCC spectrum as a DFT contraction (round-1 form) instead of the FFT
   // SE gate computed inside conv2 instead of by a launch of its own (se_gate_inl.h).  Two forms were built in round 5; both give se_pre_kernel's
   // bits (tests/test_gpu_halfresnet.py) and NEITHER pays (profiles/r05_latency_matrix.txt), so the default is 0 = the launch:
   //  - prologue (3 = small grids, 4 = always; the round-4 verdict's specification: a separate instantiation in which every workgroup of an
@@ -118,8 +118,10 @@ struct xt_handle {
   //  - gate wave (1 = small grids, 2 = always; layers 1-2): a fifth wave computes the gate WHILE the four convolution waves stage the tile and
   //    run the k-loop, joining their barriers.  Concurrent, no launch -- but ONE wave walks the chain in ~10 us where the 16-wave kernel
   //    needs 1-2, longer than the convolution it hides behind: 0.636 vs 0.618 ms.
-  int gate_prologue = getenv("SIDEKIT_AMD_GATE_PROLOGUE") ? atoi(getenv("SIDEKIT_AMD_GATE_PROLOGUE")) : 0;
-  // small-grid tilings for conv2 of layers 3-4 (conv3x3.hip, "Small-grid forms"): 1 (default) at most 12 utterances, 0 never, 2 always
+  int gate_prologue = SK_AB_ENV_INT("SIDEKIT_AMD_GATE_PROLOGUE", 0);   // A/B builds only: the product has no in-convolution gate form
+  // small-grid tilings for conv2 of layers 3-4 (conv3x3.hip, "Small-grid forms"): 1 (default) at most SMALL_GRID_MAX_B utterances, 0 never, 2 always
+  static constexpr int SMALL_GRID_MAX_B = 12;      // crossover with the product tilings between 12 and 16 utterances (profiles/r05_small_grid_sweep.txt)
+  static constexpr int GATE_AB_MAX_B = 8;          // A/B builds: the in-convolution gate forms keep their own bound (SIDEKIT_AMD_GATE_PROLOGUE = 1 / 3)
   int small_grid = getenv("SIDEKIT_AMD_SMALL_GRID") ? atoi(getenv("SIDEKIT_AMD_SMALL_GRID")) : 1;
   xt_config cfg;
   int device = 0;
@@ -672,7 +674,7 @@ static int frontend_rows(xt_handle* h, Lane& ln, const void* d_wav, int pcm16, i
     p.a_mode = A_PLAIN; p.A = ln.ws_S.p; p.lda = h->nbp; p.a_rows = M;
   } else {
     // 1) frames x DFT basis -> [re | im]   (A/B form of the MFCC front-end: n_fft 2048, win 1024)
-    SK_CHECK(!pcm16, SK_EARG, "the DFT-GEMM A/B form of the MFCC front-end (SIDEKIT_AMD_MFCC_DFT_GEMM) takes float32 samples only");
+    SK_CHECK(!pcm16, SK_EARG, "the DFT-GEMM A/B form of the MFCC front-end takes float32 samples only");
     GemmArgs g = gemm_args();
     g.a_mode = A_FRAMES; g.A = d_wav; g.wav_ld = wav_ld; g.window = h->d_window; g.nsamples = m.d_nsamples;
     g.nsamples_uniform = m.nsamples_uniform; g.hop = f.hop; g.t_max = m.T; g.row_b = m.d_row_b; g.row_t = m.d_row_t;
@@ -748,7 +750,7 @@ static int half_from_feats(xt_handle* h, Lane& ln, const float* feats, long sb, 
     // shortcut rides on conv1's centre tap where that costs no occupancy (the stride-2 shapes already run one workgroup per CU)
     // first block of a layer: by default conv2's epilogue evaluates the 1x1 shortcut conv itself from the block input
     // (no shortcut tensor at all); the older forms -- riding on conv1's centre tap, or a separate 1x1 launch -- remain
-    // for A/B runs (SIDEKIT_AMD_SHORTCUT_TENSOR=1)
+    // in A/B builds (make ab; SIDEKIT_AMD_SHORTCUT_TENSOR=1)
     const bool inplace_sc = first && !h->shortcut_tensor;
     const bool fuse_sc = first && !inplace_sc && b.c1.g.stride == 2 && b.c1.g.nw == 1 && b.sc.g.ck == b.c1.g.ck && !b.c1.g.m16;   // (the 16x16x32 k-loop has no fused-shortcut form)
     if (fuse_sc) { a.sc_wpack = b.sc.wpack; a.sc_scale = b.sc.scale; a.sc_shift = b.sc.shift; a.sc_out = SC; }
@@ -776,13 +778,15 @@ static int half_from_feats(xt_handle* h, Lane& ln, const float* feats, long sb, 
       a.se_part = nullptr; a.col_part = nullptr; a.edge = nullptr; a.relu = 0;
       { ProfScope ps(h, b.sc.shape, st); SK_TRY(launch_conv(b.sc.shape, dt, a, st)); }
     }
-    // small grids (at most 12 utterances; 1 is the reference driver's call shape, sidekit/bin/extract_xvectors.py:146): a forward is a
+    // small grids (at most SMALL_GRID_MAX_B utterances; 1 is the reference driver's call shape, sidekit/bin/extract_xvectors.py:146): a forward is a
     // chain of dependent launches, each as long as ONE wave's work: conv2 of layers 3-4 runs in 3- / 2-row tiles (more, shorter workgroups).  Same bits.
-    const bool small = dt == DT_BF16 && (h->small_grid == 2 || (h->small_grid == 1 && B <= 12 && (long)B * Hl[li] <= 4096));   // crossover between 12 and 16 utterances (profiles/r05_small_grid_sweep.txt)
+    // (A/B builds: a SIDEKIT_AMD_SHAPE_MAP may remap conv2's shape to a geometry the T shapes' weight pack does not match -- no small grids then.)
+    const bool small = dt == DT_BF16 && !SK_AB_GETENV("SIDEKIT_AMD_SHAPE_MAP") &&
+                       (h->small_grid == 2 || (h->small_grid == 1 && B <= xt_handle::SMALL_GRID_MAX_B && (long)B * Hl[li] <= 4096));
     const int c2shape = !small ? b.c2.shape : (li == 2 ? (int)CONV_L3T : (li == 3 ? (int)CONV_L4T : b.c2.shape));
     // the gate inside conv2 (A/B forms, off by default: see xt_handle::gate_prologue).  1 / 2: layers 1-2, conv2's fifth wave computes it beside the k-loop
     // (small grids / always); 3 / 4: every layer, every workgroup computes it before its k-loop (small grids / always)
-    const bool small_b = B <= 8 && (long)B * Hl[li] <= 4096;
+    const bool small_b = B <= xt_handle::GATE_AB_MAX_B && (long)B * Hl[li] <= 4096;
     const int gate_pro = (h->gate_prologue == 2 || (h->gate_prologue == 1 && small_b)) ? (b.C <= 64 ? 2 : 0)
                          : ((h->gate_prologue == 4 || (h->gate_prologue == 3 && small_b)) ? 1 : 0);
     if (!gate_pro) {
@@ -823,7 +827,7 @@ static int half_from_feats(xt_handle* h, Lane& ln, const float* feats, long sb, 
   g1.M = R; g1.N = 128; g1.K = D; g1.rowbias = (const float*)ln.ws_rb.p; g1.rows_per_group = H4;
   g1.act = ACT_RELU_BN_TANH; g1.scale = h->att_bn_scale; g1.shift = h->att_bn_shift; g1.W_bf16 = h->att_w1x_bf16;
   SK_TRY(launch_gemm(g1, st));
-  if (xbf && !getenv("SIDEKIT_AMD_ATT_SEPARATE")) {   // bf16 path: attention.4 + softmax + statistics fused, e never leaves the accumulators
+  if (xbf && !SK_AB_GETENV("SIDEKIT_AMD_ATT_SEPARATE")) {   // bf16 path: attention.4 + softmax + statistics fused, e never leaves the accumulators
     SK_TRY(launch_att_fused(X, (const float*)ln.ws_h.p, h->att_w2_bf16, h->att_b2, D, D, rs, (float*)ln.ws_pooled.p, B, st));
   } else {
   GemmArgs g2 = gemm_args();  // attention.4
@@ -1088,8 +1092,8 @@ static int reserve_side_lanes(xt_handle* h, int32_t max_batch, int64_t max_sampl
       // SLOWER than the serial one (round 4, one rank under torch.distributed.run: 6.41-6.60 vs 5.93-6.08 ms,
       // scripts/rccl_step_probe.py).  Queues are pooled per priority, so lanes of another priority get queues of their own; and
       // they must all have the SAME priority: one high-priority lane beside the caller's normal stream ran ahead of it instead of
-      // beside it and the overlap was gone (5.92 vs 5.73 ms).  SIDEKIT_AMD_LANE_PRIORITY = low (default) | high | normal.
-      static const char* pe = getenv("SIDEKIT_AMD_LANE_PRIORITY");
+      // beside it and the overlap was gone (5.92 vs 5.73 ms).  Product: low; A/B builds: SIDEKIT_AMD_LANE_PRIORITY = low | high | normal.
+      static const char* pe = SK_AB_GETENV("SIDEKIT_AMD_LANE_PRIORITY");
       int least = 0, greatest = 0;
       SK_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
       const int prio = (pe && !strcmp(pe, "normal")) ? 0 : ((pe && !strcmp(pe, "high")) ? greatest : least);
@@ -1234,7 +1238,7 @@ int xt_forward_pcm16(xt_handle* h, const int16_t* d_pcm, int64_t pcm_ld, const i
 static int reserve_slot(xt_handle* h, int slot, int32_t max_batch, int64_t max_samples) {
   Lane& lk = h->lane[slot];
   if (!lk.stream) {
-    static const char* pe = getenv("SIDEKIT_AMD_LANE_PRIORITY");
+    static const char* pe = SK_AB_GETENV("SIDEKIT_AMD_LANE_PRIORITY");
     int least = 0, greatest = 0;
     SK_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
     const int prio = (pe && !strcmp(pe, "normal")) ? 0 : ((pe && !strcmp(pe, "high")) ? greatest : least);
@@ -1269,7 +1273,7 @@ int xt_forward_begin(xt_handle* h, int32_t slot, const void* d_wav, int32_t in_d
   StreamScope scope_(h, (hipStream_t)stream);
   SK_HIP(hipEventRecord(lk.fork, (hipStream_t)stream));
   SK_HIP(hipStreamWaitEvent(lk.stream, lk.fork, 0));
-  static const int cap = getenv("SIDEKIT_AMD_SLOT_PERSIST_CAP") ? atoi(getenv("SIDEKIT_AMD_SLOT_PERSIST_CAP")) : 1;
+  static const int cap = SK_AB_ENV_INT("SIDEKIT_AMD_SLOT_PERSIST_CAP", 1);
   lk.persist_cap = cap;
   BatchMeta m;
   int rc = lane_frontend(h, lk, d_wav, in_dtype == XT_I16 ? 1 : 0, wav_ld, h_nsamples, B, L, m, lk.stream);

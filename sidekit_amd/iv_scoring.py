@@ -106,12 +106,14 @@ def plda_matrix(enroll_vectors, test_vectors, Phi, Psi, cst, scaling_factor=1., 
 HIST_BINS = 8192
 
 
-def cosine_histograms(enroll_vectors, test_vectors, enroll_labels, test_labels, self_offset=None, lo=-1.0, hi=1.0, device=None):
+def cosine_histograms(enroll_vectors, test_vectors, enroll_labels, test_labels, self_offset=None, lo=-1.0, hi=1.0, device=None, bins=None):
     """Target / non-target score histograms of ALL (enrol, test) pairs without materialising the (Ne, Nt) score matrix
     (SURVEY 8d: 100k x 100k cosine trials are 40 GB).  A trial is a target when the two integer labels are equal;
     ``self_offset=k`` drops the self-trials ``j == i + k`` when the enrolment side is rows ``[k, k + Ne)`` of the test side (``0`` for
     a set scored against itself, a shard's first row for one rank's block of it); ``None`` keeps every pair.  Returns two uint64 arrays of
-    ``HIST_BINS`` equal bins over ``[lo, hi)``; ``bosaris.detplot.eer_from_histograms`` turns them into the ROCCH EER."""
+    ``bins`` equal bins over ``[lo, hi)`` (scores outside land in the end bins); ``bosaris.detplot.eer_from_histograms`` turns them into the
+    ROCCH EER.  ``bins``: ``HIST_BINS`` (8192, the kernel's LDS histograms: one pass over the pairs) or a multiple of ``HIST_BINS - 2``: that
+    many finer bins from ``bins / (HIST_BINS - 2)`` passes, each over a slice of the range with one guard bin either side."""
     device = _device(device if device is not None else (enroll_vectors.device if torch.is_tensor(enroll_vectors) and enroll_vectors.is_cuda else None))
     e, t = _to_device(enroll_vectors, torch.float32, device), _to_device(test_vectors, torch.float32, device)
     if e.shape[1] % 4 or e.shape[1] != t.shape[1]:
@@ -119,13 +121,37 @@ def cosine_histograms(enroll_vectors, test_vectors, enroll_labels, test_labels, 
     le = torch.as_tensor(enroll_labels).to(device=device, dtype=torch.int32).contiguous()
     lt = torch.as_tensor(test_labels).to(device=device, dtype=torch.int32).contiguous()
     assert le.shape == (e.shape[0],) and lt.shape == (t.shape[0],), "one label per vector"
-    ht = torch.empty(HIST_BINS, dtype=torch.int64, device=device)
-    hn = torch.empty(HIST_BINS, dtype=torch.int64, device=device)
-    with torch.cuda.device(device):
-        _lib.check(_lib.lib().sc_cosine_hist(e.data_ptr(), e.shape[0], t.data_ptr(), t.shape[0], e.shape[1], le.data_ptr(), lt.data_ptr(),
-                                             -1 if self_offset is None else int(self_offset), float(lo), float(hi), HIST_BINS, ht.data_ptr(), hn.data_ptr(),
-                                             _stream(device)), AssertionError)
-    return ht.cpu().numpy().astype(numpy.uint64), hn.cpu().numpy().astype(numpy.uint64)
+    bins = HIST_BINS if bins is None else int(bins)
+    inner = HIST_BINS - 2
+    if bins != HIST_BINS and (bins <= 0 or bins % inner):
+        raise AssertionError(f"bins must be {HIST_BINS} or a multiple of {inner}")
+    if not float(hi) > float(lo):
+        raise AssertionError("histogram range: hi must exceed lo")
+
+    def one_pass(a, b):
+        ht = torch.empty(HIST_BINS, dtype=torch.int64, device=device)
+        hn = torch.empty(HIST_BINS, dtype=torch.int64, device=device)
+        with torch.cuda.device(device):
+            _lib.check(_lib.lib().sc_cosine_hist(e.data_ptr(), e.shape[0], t.data_ptr(), t.shape[0], e.shape[1], le.data_ptr(), lt.data_ptr(),
+                                                 -1 if self_offset is None else int(self_offset), float(a), float(b), HIST_BINS, ht.data_ptr(), hn.data_ptr(),
+                                                 _stream(device)), AssertionError)
+        return ht.cpu().numpy().astype(numpy.uint64), hn.cpu().numpy().astype(numpy.uint64)
+
+    if bins == HIST_BINS:
+        return one_pass(lo, hi)
+    w = (float(hi) - float(lo)) / bins
+    out_t, out_n = numpy.zeros(bins, dtype=numpy.uint64), numpy.zeros(bins, dtype=numpy.uint64)
+    passes = bins // inner
+    for k in range(passes):
+        a = float(lo) + k * inner * w
+        ht, hn = one_pass(a - w, a + (inner + 1) * w)          # bins 0 and HIST_BINS - 1 of a pass: everything below / above its slice
+        for full, part in ((out_t, ht), (out_n, hn)):
+            full[k * inner:(k + 1) * inner] = part[1:-1]
+            if k == 0:
+                full[0] += part[0]
+            if k == passes - 1:
+                full[-1] += part[-1]
+    return out_t, out_n
 
 
 def _speaker_posterior_terms(K):

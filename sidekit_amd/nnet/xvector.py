@@ -201,7 +201,8 @@ class Xtractor:
             lib.xt_forward_end(h, slot, self._stream(x))
             raise (ValueError if rc == _lib.SK_EARG else RuntimeError)(msg)
         self._next_slot = (slot + 1) % self.pipeline_depth
-        ticket = (h, slot, x, logits, emb)        # x is kept alive until the forward that reads it has been waited for
+        # x is kept alive until the forward that reads it has been waited for; the submitting stream is kept because emb / logits were taken from ITS pool
+        ticket = (h, slot, x, logits, emb, torch.cuda.current_stream(x.device))
         self._tickets.append(ticket)
         return ticket
 
@@ -209,8 +210,19 @@ class Xtractor:
         """Make the current stream wait for the oldest submitted batch and return what ``forward`` returns for it."""
         if not self._tickets or self._tickets[0] is not ticket:
             raise RuntimeError("collect: tickets are collected in submission order")
-        h, slot, x, logits, emb = self._tickets.pop(0)
-        _lib.check(_lib.lib().xt_forward_end(h, slot, self._stream(emb)))
+        h, slot, x, logits, emb, sub = self._tickets.pop(0)
+        lib = _lib.lib()
+        cur = torch.cuda.current_stream(emb.device)
+        _lib.check(lib.xt_forward_end(h, slot, ctypes.c_void_p(cur.cuda_stream)))
+        if cur != sub:
+            # Collected on another stream than the one it was submitted on.  emb / logits (and, usually, x) are blocks of the SUBMITTING stream's
+            # pool: once the caller drops them the caching allocator hands them out again on that stream at once -- which so far knows neither
+            # of the slot's forward (still writing emb, still reading x) nor of what the collecting stream does with the results.  So the
+            # submitting stream waits for the slot as well (one hipStreamWaitEvent), and the outputs are recorded as in use on this stream.
+            _lib.check(lib.xt_forward_end(h, slot, ctypes.c_void_p(sub.cuda_stream)))
+            emb.record_stream(cur)
+            if logits is not None:
+                logits.record_stream(cur)
         return (logits, emb) if self.loss == "aam" else emb
 
     def discard_pending(self):

@@ -62,9 +62,10 @@ def _needs_a_gpu():
 def test_bench_one_rank_over_rccl_matches_the_plain_run():
     """bench.py as the driver launches it for N > 1 (torch.distributed.run), with one rank: the RCCL all-gather of every step's
     x-vectors is issued on RCCL's stream and ordered behind / ahead of the forwards as bench.py:step() says; the gathered block must
-    equal the local one (asserted inside bench.py).  The two step times are REPORTED (round 4 observed a ratio of 1.02-1.03): they come
-    from two cold processes on a chip whose clock a power governor sets, so only a gross stall of the step behind the collective -- the
-    defect round 4 found, 1.14 x -- is an error, as a one-sided bound."""
+    equal the local one (asserted inside bench.py).  The step behind the collective must not stall: round 4 found exactly that defect at
+    1.14 x the plain step and observed 1.02-1.03 once it was fixed, so the bound is 1.12, one-sided.  The two numbers come from two cold
+    processes on a chip whose clock a power governor sets; each run times FIVE regions of K steps (bench.py `regions_ms`), and the ratio is
+    taken between the two runs' FASTEST regions -- a stall behind the collective is in every region, a cold clock is not."""
     common = ["bench.py", "--gpus", "1", "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--no-profile"]
     d = _json_line(_torchrun(common))
     p = _json_line(_plain(common))
@@ -72,9 +73,11 @@ def test_bench_one_rank_over_rccl_matches_the_plain_run():
     assert "2 batches in flight" in d["config"]["pipeline"] and d["config"]["lanes"] == 1
     assert d["n_gpus"] == 1 and d["steps"] == 20 and d["dtype"] == "bf16" and d["scaling"] == "weak"
     assert d["value"] > 0 and abs(d["value"] - 256 * 1000.0 / d["ms_per_step"]) / d["value"] < 1e-6
-    ratio = d["ms_per_step"] / p["ms_per_step"]
-    print(f"ms_per_step: torch.distributed.run x1 + RCCL gather {d['ms_per_step']:.3f}, plain {p['ms_per_step']:.3f}, ratio {ratio:.3f}")
-    assert ratio < 1.30, f"the all-gather stalls the step: {d['ms_per_step']:.3f} vs {p['ms_per_step']:.3f} ms"
+    best_d, best_p = min(d["regions_ms"]), min(p["regions_ms"])          # per-step milliseconds of each region
+    ratio = best_d / best_p
+    print(f"ms_per_step (fastest of five regions): torch.distributed.run x1 + RCCL gather {best_d:.3f}, plain {best_p:.3f}, ratio {ratio:.3f}; "
+          f"medians {d['ms_per_step']:.3f} / {p['ms_per_step']:.3f}")
+    assert ratio < 1.12, f"the all-gather stalls the step: {best_d:.3f} vs {best_p:.3f} ms (round 4's defect was 1.14 x)"
 
 
 def test_extract_xvectors_cli_one_rank_over_rccl(tmp_path):

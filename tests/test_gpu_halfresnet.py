@@ -238,8 +238,9 @@ def test_bf16_row_tile_boundaries_and_per_utterance(model):
         model.compute_dtype = "fp32"
 
 
+@pytest.mark.ab_variant
 def test_ab_paths_agree(gpu, monkeypatch):
-    """The A/B switches kept in the library (shortcut as a stored tensor / mel projection as a GEMM) are the older
+    """The A/B switches of the -DSK_AB build (shortcut as a stored tensor / mel projection as a GEMM / attention unfused) are the older
     formulations of the same arithmetic: they must agree with the default path (bf16 bit for bit on the shortcut side)."""
     torch.manual_seed(21)
     wav = 0.1 * torch.randn(3, 30000).cuda()
@@ -273,7 +274,7 @@ def test_profile_slots(model):
     model(wav, is_eval=True)
     full = model.get_profile(reset=True)
     assert {"conv_L1", "conv_L4", "frontend", "stem", "se_residual", "pool_tail"} <= set(full) and full["conv_L1"][1] == 6 and full["se_residual"][1] == 16
-    model(wav[:2], is_eval=True)                      # at most 8 utterances: conv2 of layers 3-4 runs its small-grid tiling, booked under the same class
+    model(wav[:2], is_eval=True)                      # at most 12 utterances: conv2 of layers 3-4 runs its small-grid tiling, booked under the same class
     small = model.get_profile(reset=True)
     assert small["se_residual"][1] == 16 and small["conv_L1"][1] == 6 and small["conv_L3"][1] == 11 and small["conv_L4"][1] == 5
     model.set_profile(True, slots=["stem", "conv_L3"])
@@ -298,35 +299,51 @@ def test_embedding_does_not_depend_on_the_batch_size(gpu):
         assert torch.equal(big, parts), (dt, float((big - parts).abs().max()))
 
 
-def test_small_grid_forms_give_the_bits_of_the_batch_forms(gpu, monkeypatch):
-    """Small batches (<= 8 utterances: the reference driver's call shape, sidekit/bin/extract_xvectors.py:146) run conv2 of layers 3-4 in 3- / 2-row
-    tiles (csrc/conv3x3.hip, "Small-grid forms").  Two ways of computing the SE gate INSIDE conv2 instead of by the launch of ``se_pre_kernel``
-    between conv1 and conv2 (sidekit/nnet/res_net.py:272-281,316-319) exist beside that (csrc/se_gate_inl.h; measured, off by default): a
-    fifth wave of conv2 (layers 1-2) and a prologue in which every workgroup of an utterance walks the 1024 virtual threads of
-    ``se_pre_kernel`` on its 256 real ones (every layer).  Forced on / off on models with the same weights (SIDEKIT_AMD_SMALL_GRID,
-    SIDEKIT_AMD_GATE_PROLOGUE), x-vectors and logits are the same bits at every batch size -- batch 1 at 4 s and 45 s (563 row tiles), ragged
-    batches, a batch of 40 -- in both precisions; and the automatic choice agrees with all of them."""
+SMALL_GRID_CASES = [(1, 64000, False), (1, 45 * 16000, False), (3, 48000, True), (8, 64000, False), (8, 160000, True), (12, 64000, False), (13, 64000, False),
+                    (12, 48000, True), (40, 32000, True)]     # 12 / 13: either side of xt_handle::SMALL_GRID_MAX_B (csrc/xt_api.hip)
+
+
+def _small_grid_check(gpu, monkeypatch, settings, cases):
+    """models with the same weights under each (SIDEKIT_AMD_SMALL_GRID, SIDEKIT_AMD_GATE_PROLOGUE) setting -> same bits as the first one, every case, both precisions"""
     models = {}
-    for mode, gate in (("0", "0"), ("2", "2"), ("1", "1"), ("4", "4")):    # gate: 2 = the fifth-wave form (layers 1-2) always, 4 = the prologue form (every layer) always
+    for key, (grid, gate) in settings.items():
         monkeypatch.setenv("SIDEKIT_AMD_GATE_PROLOGUE", gate)
-        monkeypatch.setenv("SIDEKIT_AMD_SMALL_GRID", "1" if mode == "4" else mode)
+        monkeypatch.setenv("SIDEKIT_AMD_SMALL_GRID", grid)
         m = Xtractor(64, model_archi="halfresnet34", loss="aam", seed=41).to(gpu).eval()
         m.compute_dtype = "fp32"; m(torch.zeros(1, 4000, device="cuda") + 0.01, is_eval=True)      # the handles are created under this setting
         m.compute_dtype = "bf16"; m(torch.zeros(1, 4000, device="cuda") + 0.01, is_eval=True)
-        models[mode] = m
+        models[key] = m
+    ref = next(iter(models))
     g = torch.Generator(device="cuda").manual_seed(17)
-    cases = [(1, 64000, False), (1, 45 * 16000, False), (3, 48000, True), (8, 64000, False), (8, 160000, True), (40, 32000, True)]
     for B, L, ragged in cases:
         wav = 0.1 * torch.randn(B, L, device="cuda", generator=g)
         lens = torch.randint(L // 4, L + 1, (B,), generator=torch.Generator().manual_seed(B * 7 + 1)).tolist() if ragged else None
         for dt in ("bf16", "fp32"):
             outs = {}
-            for mode, m in models.items():
+            for key, m in models.items():
                 m.compute_dtype = dt
-                outs[mode] = m(wav, is_eval=True, lengths=lens)
-            for mode in ("2", "1", "4"):
-                assert torch.equal(outs[mode][1], outs["0"][1]) and torch.equal(outs[mode][0], outs["0"][0]), (B, L, ragged, dt, mode)
+                outs[key] = m(wav, is_eval=True, lengths=lens)
+            for key in models:
+                assert torch.equal(outs[key][1], outs[ref][1]) and torch.equal(outs[key][0], outs[ref][0]), (B, L, ragged, dt, key)
     torch.cuda.synchronize()
+
+
+def test_small_grid_forms_give_the_bits_of_the_batch_forms(gpu, monkeypatch):
+    """Small batches (at most 12 utterances, xt_handle::SMALL_GRID_MAX_B; 1 is the reference driver's call shape, sidekit/bin/extract_xvectors.py:146) run
+    conv2 of layers 3-4 in 3- / 2-row tiles (csrc/conv3x3.hip, "Small-grid forms").  Forced off / on and chosen automatically (SIDEKIT_AMD_SMALL_GRID = 0 /
+    2 / 1) on models with the same weights, x-vectors and logits are the same bits at every batch size -- batch 1 at 4 s and 45 s (563 row tiles), ragged
+    batches, batches of 12 and 13 (either side of the threshold), a batch of 40 -- in both precisions."""
+    _small_grid_check(gpu, monkeypatch, {"never": ("0", "0"), "always": ("2", "0"), "auto": ("1", "0")}, SMALL_GRID_CASES)
+
+
+@pytest.mark.ab_variant
+def test_in_convolution_gate_forms_give_the_bits_of_the_launch(gpu, monkeypatch):
+    """A/B build only (csrc/se_gate_inl.h; both forms measured slower than the launch in round 5): two ways of computing the SE gate
+    INSIDE conv2 instead of by the launch of ``se_pre_kernel`` between conv1 and conv2 (sidekit/nnet/res_net.py:272-281,316-319) -- a fifth wave of
+    conv2 (layers 1-2) and a prologue in which every workgroup of an utterance walks the 1024 virtual threads of ``se_pre_kernel`` on its 256 real ones
+    (every layer; selected for at most 8 utterances, xt_handle::GATE_AB_MAX_B, or always).  Same bits as the launch at every batch size."""
+    _small_grid_check(gpu, monkeypatch, {"launch": ("0", "0"), "wave always": ("2", "2"), "wave small": ("1", "1"), "prologue always": ("1", "4"), "prologue small": ("1", "3")},
+                      [c for c in SMALL_GRID_CASES if c[0] != 13])
 
 
 def test_very_short_clips_as_the_first_call(gpu):

@@ -61,6 +61,41 @@ def test_calls_from_different_streams_are_ordered_by_the_library(gpu):
     assert bad == 0, f"{bad} of 60 results differ from the one-at-a-time reference"
 
 
+def test_submit_on_one_stream_collect_on_another_then_drop_the_outputs(gpu):
+    """submit on stream A, collect on stream B, drop the outputs, then allocate-and-fill tensors of the same sizes on A: the caching allocator
+    hands A the blocks the dropped outputs occupied (they came from A's pool), so A must have been ordered behind the slot's forward by
+    ``collect`` -- else the fill races the forward that is still writing them (``Xtractor.collect``: the submitting stream waits for the slot
+    as well, the outputs are ``record_stream``-ed on the collecting one).  A second batch in flight meanwhile must come out as the
+    one-at-a-time reference has it, and so must the first one when it is NOT dropped."""
+    dev = torch.device(gpu)
+    a = Xtractor(64, model_archi="halfresnet34", loss="aam", seed=33).to(dev).eval()
+    ref = Xtractor(64, model_archi="halfresnet34", loss="aam", seed=33).to(dev).eval()
+    a.compute_dtype = ref.compute_dtype = "bf16"
+    ref.set_lanes(1)
+    g = torch.Generator(device=dev).manual_seed(9)
+    w = [_wav(g, 256, 32000, dev) for _ in range(2)]
+    want = [tuple(t.clone() for t in ref(x, is_eval=True)) for x in w]
+    a.collect(a.submit(w[0]))
+    torch.cuda.synchronize()
+    A, B = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+    with torch.cuda.stream(A):
+        t0 = a.submit(w[0])
+        t1 = a.submit(w[1])
+    with torch.cuda.stream(B):
+        l0, e0 = a.collect(t0)
+        keep = (l0.clone(), e0.clone())          # read on B, behind the slot
+    shapes = (tuple(l0.shape), tuple(e0.shape))
+    del l0, e0, t0                               # the blocks go back to A's pool while batch 1 (and, without the fix, batch 0's tail) may still run
+    with torch.cuda.stream(A):
+        junk = [torch.full(sh, 7.0, device=dev) for sh in shapes for _ in range(4)]     # same sizes: the allocator reuses the freed blocks
+    with torch.cuda.stream(B):
+        l1, e1 = a.collect(t1)
+    torch.cuda.synchronize()
+    assert torch.equal(keep[0], want[0][0]) and torch.equal(keep[1], want[0][1]), "the batch collected on B differs from the reference"
+    assert torch.equal(l1, want[1][0]) and torch.equal(e1, want[1][1]), "the second batch differs from the reference"
+    assert all(bool((j == 7.0).all()) for j in junk), "a fill on the submitting stream was overwritten by the forward it should have been ordered behind"
+
+
 def test_two_threads_in_one_handle_are_refused_not_raced(gpu):
     """Two host threads drive ONE model at once (ctypes releases the interpreter lock inside a call, so they really are inside the library
     together): every call either returns the right x-vectors or raises the SK_ESTATE error -- nothing is enqueued by the refused call, and the

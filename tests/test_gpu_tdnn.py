@@ -81,6 +81,7 @@ def test_wav_variable_length_batch(gpu, fx):
             m.compute_dtype = None
 
 
+@pytest.mark.ab_variant
 def test_mfcc_fft_matches_the_dft_contraction(gpu, fx, monkeypatch):
     """The MFCC spectrum as a 2048-point real FFT (frontend_fft.hip) against the round-1 form, a (frames x 1024) x (1024 x 2050)
     DFT contraction on the exact-f32 matrix cores (SIDEKIT_AMD_MFCC_DFT_GEMM=1), and both against the oracle: ragged lengths
@@ -103,6 +104,7 @@ def test_mfcc_fft_matches_the_dft_contraction(gpu, fx, monkeypatch):
         assert rel(fa[i, :, :t], ofe.mfcc_frontend(wav[i:i + 1, :n])[0]) < TOL, (i, n)
 
 
+@pytest.mark.ab_variant
 def test_large_gemm_tiling_is_bit_identical(gpu, fx, monkeypatch):
     """128 x 128 tiles (problems of >= 2048 rows) against the 64 x 64 kernel (SIDEKIT_AMD_GEMM64=1): the same k-ordered FMA
     chain per output element, so the TDNN forward of a 40-utterance ragged batch (7k rows) must not move by one bit."""
