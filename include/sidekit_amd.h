@@ -145,14 +145,16 @@ int xt_debug_tap(xt_handle* h, const char* name, void* h_dst, size_t capacity, s
 #define XT_PROF_SE_RES 13
 #define XT_PROF_POOL_TAIL 14
 #define XT_PROF_TDNN 15
-#define XT_PROF_SLOTS 16
+#define XT_PROF_PAIR_L1 16   /* conv2 of block k + conv1 of block k + 1 of layer 1 in one kernel (round 6; csrc/conv_pair.hip) */
+#define XT_PROF_SLOTS 17
 int xt_set_profile(xt_handle* h, int32_t on);
 int xt_get_profile(xt_handle* h, double* ms /*[XT_PROF_SLOTS]*/, int64_t* launches /*[XT_PROF_SLOTS]*/, int32_t reset);
 
 /* Tuning harness (diagnostic): mean device ms of `iters` launches of trunk convolution `shape` (slot order of
  * xt_get_profile) on a B x T batch; variant bit0 = no stores, bit1 = no MFMA loop, bit2 = no staging, bit3 = statistics epilogue, bit4 = residual epilogue,
- * bit5 = one workgroup per tile even for the persistent shapes, bit6 = print the runtime's occupancy for the shape; shapes 11..14 are the
- * A/B alternatives listed next to the product configurations in conv3x3.hip. */
+ * bit5 = one workgroup per tile even for the persistent shapes, bit6 = print the runtime's occupancy for the shape; shapes 11..47 are the
+ * A/B alternatives listed next to the product configurations in conv3x3.hip (A/B build of the library only); shape 48 = the layer-1 pair kernel
+ * (csrc/conv_pair.hip: conv2 of block k + conv1 of block k + 1; variant bit0 = the first block's in-place shortcut form). */
 int sk_bench_conv(int32_t shape, int32_t dtype, int32_t B, int32_t T, int32_t iters, int32_t variant, float* ms_out,
                   double* phase_cycles /* [8] mean shader cycles per kernel phase, or NULL */);
 

@@ -29,9 +29,9 @@ SK_OK, SK_EARG, SK_ESHAPE, SK_EHIP, SK_EWORKSPACE, SK_ESTATE = 0, -1, -2, -3, -4
 XT_ARCH_HALFRESNET34, XT_ARCH_TDNN = 0, 1
 XT_F32, XT_BF16, XT_F64, XT_I64, XT_I16 = 0, 1, 2, 3, 4
 XT_LOSS_AAM, XT_LOSS_CCE = 0, 1
-XT_PROF_SLOTS = 16
+XT_PROF_SLOTS = 17
 PROF_NAMES = ("conv_L1", "conv_L1S", "conv_L2A", "conv_L2S", "conv_L2", "conv_L3A", "conv_L3S", "conv_L3", "conv_L4A", "conv_L4S",
-              "conv_L4", "frontend", "stem", "se_residual", "pool_tail", "tdnn")
+              "conv_L4", "frontend", "stem", "se_residual", "pool_tail", "tdnn", "conv_pair_L1")
 
 
 class XtConfig(ctypes.Structure):

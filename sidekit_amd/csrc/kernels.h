@@ -67,6 +67,31 @@ int launch_conv(int shape, int dtype, const ConvArgs& a, hipStream_t st);
 size_t conv_pack_bytes(const ConvGeom& g);
 void conv_pack_weights(const ConvGeom& g, const float* w, int kh_kw, void* dst);
 
+// ---- conv_pair.hip ------------------------------------------------------------------------
+// conv2 of BasicBlock k + conv1 of BasicBlock k + 1 of layer 1 in one kernel (bf16): the block output Y_k passes from conv2's epilogue to conv1's
+// k-loop through LDS and is written to HBM once, never read back (res_net.py:309-320, two consecutive blocks).  Same numbers, bit for bit, as
+// launch_conv(residual form) followed by launch_conv(statistics form).
+struct ConvPairArgs {
+  int C, W;              // geometry: 32 channels x 80 columns (layer 1) is what is built
+  // -- conv2 of block k (residual form)
+  const void* in;        // O1_k  [B][H][W][C] bf16: conv1_k's output
+  const void* w2pack;    // conv2_k weights, fragment order (conv_pack_weights, the layer's stride-1 shape)
+  const float* scale2; const float* shift2;   // bn2_k folded
+  const float* gate;     // [B][C] SE gate of block k (launch_se_pre)
+  const void* shortcut;  // X_k [B][H][W][C] bf16: the block input (identity shortcut) -- or nullptr with the in-place 1x1 shortcut below
+  const void* sc_in; const void* sc_wpack; const float* sc_shift;   // first block of the layer: x_in, folded 1x1 weights, shortcut BatchNorm shift
+  void* y_out;           // Y_k [B][H][W][C] bf16
+  // -- conv1 of block k + 1 (statistics form)
+  const void* w1pack; const float* scale1; const float* shift1;
+  void* o_out;           // O1_{k+1}
+  float* se_part; float* col_part; float* edge;   // as ConvArgs (tiles of 8 rows, 4 wave rows)
+  const void* zeros;
+  Lens lens;             // rows per utterance (layer 1: the feature frames)
+  int B, H;              // utterances, allocated rows
+  int persist_cap;
+};
+int launch_conv_pair(const ConvPairArgs& a, hipStream_t st);
+
 // ---- trunk_misc.hip -----------------------------------------------------------------------
 // stem: features (strides sf, st in elements) -> relu(bn(conv3x3 1->32)) NHWC [B][T][80][32]; w = tap-major [9][32] weights with the
 // BatchNorm scale folded in, shift = the BatchNorm shift

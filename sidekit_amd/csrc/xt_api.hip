@@ -734,6 +734,10 @@ static int half_from_feats(xt_handle* h, Lane& ln, const float* feats, long sb, 
   { ProfScope ps(h, XT_PROF_STEM, st); SK_TRY(launch_stem(feats, sb, sf, stt, h->stem_w, h->stem_shift, X, dt, m.lens, B, T, st)); }
   SK_TRY(tap(h, "stem", X, act_bytes, st));
   int prev_li = 0;
+  // layer 1, bf16: conv2 of block k and conv1 of block k + 1 run as ONE kernel (conv_pair.hip) -- Y_k reaches conv1 through LDS and HBM sees 13
+  // instead of 15 activation passes for the layer.  Same bits as the two launches (A/B builds: SIDEKIT_AMD_NO_PAIR=1 runs those).
+  const bool use_pair = dt == DT_BF16 && !h->shortcut_tensor && !h->gate_prologue && !SK_AB_GETENV("SIDEKIT_AMD_NO_PAIR");
+  bool o1_ready = false;   // this block's conv1 has already run (second half of the previous block's pair kernel)
   for (size_t bi = 0; bi < h->blocks.size(); ++bi) {
     Block& b = h->blocks[bi];
     const int li = b.li;
@@ -770,7 +774,7 @@ static int half_from_feats(xt_handle* h, Lane& ln, const float* feats, long sb, 
     se.se_part = (const float*)ln.ws_se.p; se.col_part = (const float*)ln.ws_col.p; se.edge = (const float*)ln.ws_edge.p;
     se.tiles = cdiv(Hl[li], b.c1.g.th); se.wm = b.c1.g.wm; se.th = b.c1.g.th; se.w2t = b.w2t; se.w2t_bf16 = h->cfg.dtype == XT_BF16; se.scale2 = b.c2.scale; se.shift2 = b.c2.shift;
     se.fc1 = b.se_w1; se.fc2 = b.se_w2; se.gate = (float*)ln.ws_gate.p; se.lens = m.lens; se.halvings = li; se.wout = wout; se.C = b.C; se.B = B;
-    { ProfScope ps(h, b.c1.shape, st); SK_TRY(launch_conv(b.c1.shape, dt, a, st)); }
+    if (!o1_ready) { ProfScope ps(h, b.c1.shape, st); SK_TRY(launch_conv(b.c1.shape, dt, a, st)); }
     a.sc_wpack = nullptr;
     const void* shortcut = first ? SC : X;
     if (first && !fuse_sc && !inplace_sc) {  // 1x1 conv (stride s) + bn on the block input
@@ -793,6 +797,27 @@ static int half_from_feats(xt_handle* h, Lane& ln, const float* feats, long sb, 
       ProfScope ps(h, XT_PROF_SE_RES, st);
       SK_TRY(launch_se_pre(se, st));
     }
+    const bool pair = use_pair && li == 0 && bi + 1 < h->blocks.size() && h->blocks[bi + 1].li == li && (!first || inplace_sc);
+    if (pair) {
+      const Block& nb = h->blocks[bi + 1];
+      ConvPairArgs pa;
+      memset(&pa, 0, sizeof(pa));
+      pa.C = b.C; pa.W = wout;
+      pa.in = O1; pa.w2pack = b.c2.wpack; pa.scale2 = b.c2.scale; pa.shift2 = b.c2.shift; pa.gate = (const float*)ln.ws_gate.p;
+      if (first) { pa.sc_in = X; pa.sc_wpack = b.sc_wfold; pa.sc_shift = b.sc.shift; } else { pa.shortcut = X; }
+      pa.y_out = O2;
+      pa.w1pack = nb.c1.wpack; pa.scale1 = nb.c1.scale; pa.shift1 = nb.c1.shift; pa.o_out = SC;
+      pa.se_part = (float*)ln.ws_se.p; pa.col_part = (float*)ln.ws_col.p; pa.edge = (float*)ln.ws_edge.p;
+      pa.zeros = h->d_zeros; pa.lens = m.lens; pa.B = B; pa.H = Hl[li]; pa.persist_cap = ln.persist_cap;
+      { ProfScope ps(h, XT_PROF_PAIR_L1, st); SK_TRY(launch_conv_pair(pa, st)); }
+      // Y_k (O2) is the next block's input, O1_{k+1} (SC) its conv1 output; the two buffers just read are free
+      void *old_x = X, *old_o1 = O1;
+      X = O2; O1 = SC; O2 = old_x; SC = old_o1;
+      o1_ready = true;
+      prev_li = li;
+      continue;
+    }
+    o1_ready = false;
     // conv2 + bn2, * gate, + shortcut, relu -> O2 (the block output)
     a.in = O1; a.wpack = b.c2.wpack; a.scale = b.c2.scale; a.shift = b.c2.shift; a.out = O2;
     a.se_part = nullptr; a.col_part = nullptr; a.edge = nullptr; a.gate = (const float*)ln.ws_gate.p; a.shortcut = shortcut;
@@ -1382,8 +1407,61 @@ int xt_get_profile(xt_handle* h, double* ms, int64_t* launches, int32_t reset) {
 
 // Kernel-level timing harness for tuning (diagnostic; not used by the product path): runs one trunk
 // convolution shape `iters` times on zero-initialised buffers and returns the mean device time.
+// shape 48: the layer-1 pair kernel (conv_pair.hip) on random operands; variant bit 0: the first block's in-place shortcut form
+static int bench_conv_pair(int32_t B, int32_t T, int32_t iters, int32_t variant, float* ms_out) {
+  const size_t act = (size_t)B * T * 80 * 32 * 2, wbytes = 32 * 32 * 9 * 2;
+  void *bufs[4] = {nullptr, nullptr, nullptr, nullptr}, *w[3] = {nullptr, nullptr, nullptr}, *zeros = nullptr;
+  float *cst = nullptr, *gate = nullptr, *se = nullptr, *colp = nullptr, *edge = nullptr;
+  const int tiles = cdiv(T, 8);
+  for (auto& p : bufs) SK_HIP(hipMalloc(&p, act));
+  for (auto& p : w) SK_HIP(hipMalloc(&p, wbytes));
+  SK_HIP(hipMalloc(&zeros, 256)); SK_HIP(hipMemset(zeros, 0, 256));
+  SK_HIP(hipMalloc((void**)&cst, 5 * 32 * 4)); SK_HIP(hipMalloc((void**)&gate, (size_t)B * 32 * 4));
+  SK_HIP(hipMalloc((void**)&se, (size_t)B * tiles * 4 * 32 * 4)); SK_HIP(hipMalloc((void**)&colp, (size_t)B * tiles * 2 * 32 * 4)); SK_HIP(hipMalloc((void**)&edge, (size_t)B * 6 * 32 * 4));
+  {
+    uint32_t x = 0x9E3779B9u;
+    auto next = [&]() { x = x * 1664525u + 1013904223u; return (float)((x >> 8) & 0xffff) / 32768.f - 1.f; };
+    std::vector<uint16_t> hb(act / 2);
+    for (int k = 0; k < 2; ++k) {   // O1 (post-ReLU: non-negative) and the block input
+      for (auto& v : hb) { const float f = next(); v = f32_to_bf16(f < 0 ? 0.f : f); }
+      SK_HIP(hipMemcpy(bufs[k], hb.data(), act, hipMemcpyHostToDevice));
+    }
+    std::vector<uint16_t> hw(wbytes / 2);
+    for (auto& p : w) { for (auto& v : hw) v = f32_to_bf16(0.05f * next()); SK_HIP(hipMemcpy(p, hw.data(), wbytes, hipMemcpyHostToDevice)); }
+    std::vector<float> c(5 * 32);
+    for (int i = 0; i < 32; ++i) { c[i] = 1.f; c[32 + i] = 0.f; c[64 + i] = 1.f; c[96 + i] = 0.f; c[128 + i] = 0.f; }
+    SK_HIP(hipMemcpy(cst, c.data(), c.size() * 4, hipMemcpyHostToDevice));
+    std::vector<float> gv((size_t)B * 32, 0.5f);
+    SK_HIP(hipMemcpy(gate, gv.data(), gv.size() * 4, hipMemcpyHostToDevice));
+  }
+  ConvPairArgs pa;
+  memset(&pa, 0, sizeof(pa));
+  pa.C = 32; pa.W = 80; pa.in = bufs[0]; pa.w2pack = w[0]; pa.scale2 = cst; pa.shift2 = cst + 32; pa.gate = gate;
+  if (variant & 1) { pa.sc_in = bufs[1]; pa.sc_wpack = w[2]; pa.sc_shift = cst + 128; } else { pa.shortcut = bufs[1]; }
+  pa.y_out = bufs[2]; pa.w1pack = w[1]; pa.scale1 = cst + 64; pa.shift1 = cst + 96; pa.o_out = bufs[3];
+  pa.se_part = se; pa.col_part = colp; pa.edge = edge; pa.zeros = zeros; pa.lens = Lens{nullptr, T}; pa.B = B; pa.H = T;
+  hipEvent_t e0, e1;
+  SK_HIP(hipEventCreate(&e0)); SK_HIP(hipEventCreate(&e1));
+  for (int i = 0; i < 3; ++i) SK_TRY(launch_conv_pair(pa, nullptr));
+  SK_HIP(hipEventRecord(e0, nullptr));
+  for (int i = 0; i < iters; ++i) SK_TRY(launch_conv_pair(pa, nullptr));
+  SK_HIP(hipEventRecord(e1, nullptr));
+  SK_HIP(hipEventSynchronize(e1));
+  SK_HIP(hipEventElapsedTime(ms_out, e0, e1));
+  *ms_out /= iters;
+  for (auto p : bufs) (void)hipFree(p);
+  for (auto p : w) (void)hipFree(p);
+  (void)hipFree(zeros); (void)hipFree(cst); (void)hipFree(gate); (void)hipFree(se); (void)hipFree(colp); (void)hipFree(edge);
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  return SK_OK;
+}
+
 int sk_bench_conv(int32_t shape, int32_t dtype, int32_t B, int32_t T, int32_t iters, int32_t variant, float* ms_out, double* phase_cycles) {
   SK_CHECK(ms_out && B > 0 && T > 0 && iters > 0, SK_EARG, "sk_bench_conv: bad arguments");
+  if (shape == 48) {
+    SK_CHECK(dtype == XT_BF16 && !phase_cycles, SK_EARG, "sk_bench_conv: the pair kernel is bf16 only and carries no phase stamps");
+    return bench_conv_pair(B, T, iters, variant, ms_out);
+  }
   ConvGeom g;
   const int dt = dtype == XT_BF16 ? DT_BF16 : DT_F32;
   SK_TRY(conv_geom(shape, dt, &g));
