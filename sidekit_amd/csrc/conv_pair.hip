@@ -1,3 +1,8 @@
+// A/B BUILD ONLY (csrc/Makefile `make ab`; SIDEKIT_AMD_PAIR=1): built in round 6 as the round-5 verdict specified, bit-identical to the two launches it
+// replaces, and measured SLOWER than them alone and in the forward (profiles/r06_conv_pair_L1.txt has the phase stamps: the fused workgroup's chain of
+// barrier-separated memory phases is twice as long while a CU still holds only two workgroups, so the pass of HBM traffic it saves is paid for twice over
+// in exposed latency).  Kept with its test (tests/test_gpu_halfresnet.py::test_layer1_pair_kernel_gives_the_bits_of_the_two_launches) as the record.
+//
 // conv2 of BasicBlock k and conv1 of BasicBlock k + 1 in ONE kernel, layer 1 of the HalfResNet34 trunk (bf16 path): the block output Y_k
 // goes from conv2's epilogue to conv1's k-loop through LDS, so HBM sees it once (the write) instead of twice.  Reference arithmetic:
 // BasicBlock.forward, sidekit/nnet/res_net.py:309-320, two consecutive blocks of `layer1` (res_net.py:518).
@@ -86,6 +91,14 @@ __global__ __launch_bounds__(256, 2) void conv_pair_l1_kernel(ConvPairArgs a) {
   unsigned char* yout = reinterpret_cast<unsigned char*>(a.y_out);
   unsigned char* oout = reinterpret_cast<unsigned char*>(a.o_out);
 
+  auto stamp = [&](int k) {   // diagnostic path only (a.stamps == nullptr in the product)
+    if (a.stamps && tid0 == 0) {
+      unsigned long long* sp = a.stamps + (size_t)bidx * 16;
+      sp[k] = __builtin_amdgcn_s_memtime();
+      if (k == 0) sp[15] = __builtin_amdgcn_s_memrealtime();
+      if (k == 9) sp[15] = __builtin_amdgcn_s_memrealtime() - sp[15];
+    }
+  };
   auto do_item = [&](int work, bool first_item) -> bool {
     int tid = tid0;
     asm volatile("" : "+v"(tid));   // keep per-item address arithmetic out of the persistent loop's invariants (registers)
@@ -95,6 +108,7 @@ __global__ __launch_bounds__(256, 2) void conv_pair_l1_kernel(ConvPairArgs a) {
     const int hb = a.lens.get_uniform(b);        // rows of this utterance (layer 1: no halving)
     if (ho0 >= hb) return false;
     if (!first_item) __syncthreads();            // the previous item's copy-out has left the LDS
+    stamp(0);
     // ---- stage rows ho0 - 2 .. ho0 + 9 of O1
     for (int s = tid; s < PRIN * PSPP; s += 256)   // the zero position after each row
       *reinterpret_cast<uint4*>(smem + (s / PSPP) * PRS + PW * PCB + (s % PSPP) * 16) = make_uint4(0, 0, 0, 0);
@@ -108,7 +122,28 @@ __global__ __launch_bounds__(256, 2) void conv_pair_l1_kernel(ConvPairArgs a) {
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(smem + row * PRS + q * 1024), 16, 0, 0);
     }
+    // conv2's epilogue constants for this utterance, requested while the tile lands (a pass's epilogue otherwise waits one L2 round trip per channel
+    // group): residual form k1 = scale2 * gate, k0 = shift2 * gate; first-block form k0 = shift2 * gate + shift_s -- the products conv3x3.hip forms
+    // per value, formed once per channel here (the same two roundings)
+    f32x4 k1[4], k0[4];
+    {
+      const float* gate_b = a.gate + (size_t)b * PC;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale2 + 8 * g + 4 * h), sh = *reinterpret_cast<const f32x4*>(a.shift2 + 8 * g + 4 * h);
+        const f32x4 gt = *reinterpret_cast<const f32x4*>(gate_b + 8 * g + 4 * h);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { k1[g][q] = sc[q] * gt[q]; k0[g][q] = sh[q] * gt[q]; }
+        if constexpr (RSC) {
+          const f32x4 h2 = *reinterpret_cast<const f32x4*>(a.sc_shift + 8 * g + 4 * h);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) k0[g][q] = k0[g][q] + h2[q];
+        }
+      }
+    }
+    stamp(1);
     __syncthreads();
+    stamp(2);
     __builtin_amdgcn_s_setprio(0);
 
     // ================= phase A: Y rows ho0 - 1 .. ho0 + 8 =================
@@ -117,7 +152,6 @@ __global__ __launch_bounds__(256, 2) void conv_pair_l1_kernel(ConvPairArgs a) {
     // bf16 (8 registers per tile) until every wave is done with the O1 image.  Same MFMAs, same k order per tile: same bits.
     uint2 park[PMWA][4];
     {
-      const float* gate_b = a.gate + (size_t)b * PC;
       auto pos = [&](int i) { return (wm * PMWA + i) * 32 + r; };   // position in the ten-row Y tile; >= 800: none (wave 3's last tiles)
       auto pass = [&](auto i0_tag, auto n_tag) {
         constexpr int I0 = decltype(i0_tag)::value, N = decltype(n_tag)::value;
@@ -164,16 +198,11 @@ __global__ __launch_bounds__(256, 2) void conv_pair_l1_kernel(ConvPairArgs a) {
           // bn2 * gate, rounded to bf16 (conv3x3.hip `cell`, residual form, LEAN walk: per channel group, fmaf with scale * gate and shift * gate)
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
-            const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale2 + 8 * g + 4 * h), sh = *reinterpret_cast<const f32x4*>(a.shift2 + 8 * g + 4 * h);
-            const f32x4 gt = *reinterpret_cast<const f32x4*>(gate_b + 8 * g + 4 * h);
-            f32x4 sck, shk;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { sck[q] = sc[q] * gt[q]; shk[q] = sh[q] * gt[q]; }
 #pragma unroll
             for (int i = 0; i < N; ++i) {
               float v[4];
 #pragma unroll
-              for (int q = 0; q < 4; ++q) v[q] = fmaf(acc[i][4 * g + q], sck[q], shk[q]);
+              for (int q = 0; q < 4; ++q) v[q] = fmaf(acc[i][4 * g + q], k1[g][q], k0[g][q]);
               uint32_t p0 = pack_bf16x2(v[0], v[1]), p1 = pack_bf16x2(v[2], v[3]);
               asm volatile("" : "+v"(p0), "+v"(p1));   // computed HERE: the compiler otherwise sinks the arithmetic below the barrier and keeps the f32 accumulators alive through the second pass
               park[I0 + i][g] = make_uint2(p0, p1);
@@ -188,13 +217,11 @@ __global__ __launch_bounds__(256, 2) void conv_pair_l1_kernel(ConvPairArgs a) {
 #pragma unroll
           for (int ks = 0; ks < PKS; ++ks) wx[ks] = *reinterpret_cast<const uint4*>(scb + (unsigned)(ks * 1024) + lane16);
 #pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale2 + 8 * g + 4 * h), gt = *reinterpret_cast<const f32x4*>(gate_b + 8 * g + 4 * h);
+          for (int g = 0; g < 4; ++g)
 #pragma unroll
             for (int i = 0; i < N; ++i)
 #pragma unroll
-              for (int q = 0; q < 4; ++q) acc[i][4 * g + q] *= sc[q] * gt[q];
-          }
+              for (int q = 0; q < 4; ++q) acc[i][4 * g + q] *= k1[g][q];
           auto xload = [&](int i, uint4* dst) {
             const int m = pos(I0 + i);
             const int row = m / PW, col = m % PW, grow = ho0 - 1 + row;
@@ -203,27 +230,22 @@ __global__ __launch_bounds__(256, 2) void conv_pair_l1_kernel(ConvPairArgs a) {
 #pragma unroll
             for (int ks = 0; ks < PKS; ++ks) dst[ks] = ok ? *reinterpret_cast<const uint4*>(xp + ks * 32) : make_uint4(0, 0, 0, 0);
           };
-          uint4 xf[PKS], xq[PKS];
-          xload(0, xf);
+          uint4 xf[N][PKS];     // every tile's block-input fragments in flight at once: one L2 / HBM round trip per pass instead of one per tile
 #pragma unroll
-          for (int i = 0; i < N; ++i) {
-            if (i + 1 < N) xload(i + 1, xq);
+          for (int i = 0; i < N; ++i) xload(i, xf[i]);
 #pragma unroll
-            for (int ks = 0; ks < PKS; ++ks) acc[i] = mma(acc[i], wx[ks], xf[ks]);
+          for (int i = 0; i < N; ++i)
 #pragma unroll
-            for (int ks = 0; ks < PKS; ++ks) xf[ks] = xq[ks];
-          }
+            for (int ks = 0; ks < PKS; ++ks) acc[i] = mma(acc[i], wx[ks], xf[i][ks]);
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
-            const f32x4 sh = *reinterpret_cast<const f32x4*>(a.shift2 + 8 * g + 4 * h), gt = *reinterpret_cast<const f32x4*>(gate_b + 8 * g + 4 * h);
-            const f32x4 h2 = *reinterpret_cast<const f32x4*>(a.sc_shift + 8 * g + 4 * h);
 #pragma unroll
             for (int i = 0; i < N; ++i) {
               const int grow = ho0 - 1 + pos(I0 + i) / PW;
               const bool ok = grow >= 0 && grow < hb;     // rows outside the utterance: conv1's zero padding
               float v[4];
 #pragma unroll
-              for (int q = 0; q < 4; ++q) v[q] = relu_nan(acc[i][4 * g + q] + (sh[q] * gt[q] + h2[q]));
+              for (int q = 0; q < 4; ++q) v[q] = relu_nan(acc[i][4 * g + q] + k0[g][q]);
               uint32_t p0 = ok ? pack_bf16x2(v[0], v[1]) : 0u, p1 = ok ? pack_bf16x2(v[2], v[3]) : 0u;
               asm volatile("" : "+v"(p0), "+v"(p1));
               park[I0 + i][g] = make_uint2(p0, p1);
@@ -234,6 +256,24 @@ __global__ __launch_bounds__(256, 2) void conv_pair_l1_kernel(ConvPairArgs a) {
       pass(std::integral_constant<int, 0>{}, std::integral_constant<int, 4>{});
       pass(std::integral_constant<int, 4>{}, std::integral_constant<int, 3>{});
       __builtin_amdgcn_s_setprio(3);
+      stamp(3);
+    }
+    // ---- Y: (+ shortcut, ReLU,) interior rows to HBM, all ten rows stay in the image
+    {
+      constexpr int CPR = PSPP, NCH = PMTA * CPR, NIT = (NCH + 255) / 256;     // 3200 16-B chunks, 13 rounds
+      const unsigned char* scut = reinterpret_cast<const unsigned char*>(a.shortcut);
+      // chunk idx of the ten-row tile sits (idx - 80 * CPR) * 16 bytes from the first interior row in both tensors
+      const long run0 = (((long)b * a.H + ho0) * PW) * PCB - (long)PW * PCB;
+      uint4 sreg[RSC ? 1 : NIT];
+      if constexpr (!RSC) {     // the accumulators are dead: all thirteen shortcut chunks travel while the waves meet and the image is rewritten
+#pragma unroll
+        for (int q = 0; q < NIT; ++q) {
+          const int idx = tid + q * 256, grow = ho0 - 1 + idx / (PW * CPR);
+          sreg[q] = (idx < NCH && grow >= 0 && grow < hb) ? *reinterpret_cast<const uint4*>(scut + run0 + (long)idx * 16) : make_uint4(0, 0, 0, 0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      auto pos = [&](int i) { return (wm * PMWA + i) * 32 + r; };
       __syncthreads();   // every wave is done with the O1 image: Y may overwrite it
 #pragma unroll
       for (int i = 0; i < PMWA; ++i) {
@@ -245,56 +285,33 @@ __global__ __launch_bounds__(256, 2) void conv_pair_l1_kernel(ConvPairArgs a) {
           for (int g = 0; g < 4; ++g) *reinterpret_cast<uint2*>(lp + ((g ^ swz(col)) << 4)) = park[i][g];
         }
       }
-    }
-    // ---- Y: (+ shortcut, ReLU,) interior rows to HBM, all ten rows stay in the image
-    {
-      constexpr int CPR = PSPP, NCH = PMTA * CPR, NIT = (NCH + 255) / 256;     // 3200 16-B chunks, 13 rounds
-      constexpr int NH = (NIT + 1) / 2;                                         // shortcut chunks are fetched in two batches (registers)
-      const unsigned char* scut = reinterpret_cast<const unsigned char*>(a.shortcut);
-      // chunk idx of the ten-row tile sits (idx - 80 * CPR) * 16 bytes from the first interior row in both tensors
-      const long run0 = (((long)b * a.H + ho0) * PW) * PCB - (long)PW * PCB;
-      uint4 sreg[RSC ? 1 : NH];
-      auto fetch = [&](int q0, int q1) {
-        if constexpr (!RSC) {
-#pragma unroll
-          for (int q = q0; q < q1; ++q) {
-            const int idx = tid + q * 256, grow = ho0 - 1 + idx / (PW * CPR);
-            sreg[q - q0] = (idx < NCH && grow >= 0 && grow < hb) ? *reinterpret_cast<const uint4*>(scut + run0 + (long)idx * 16) : make_uint4(0, 0, 0, 0);
-          }
-        }
-      };
-      auto finish = [&](int q0, int q1) {
-#pragma unroll
-        for (int q = q0; q < q1; ++q) {
-          const int idx = tid + q * 256;
-          if (idx >= NCH) break;
-          const int p = idx / CPR, cc = idx % CPR, row = p / PW, col = p % PW, grow = ho0 - 1 + row;
-          const bool ok = grow >= 0 && grow < hb;
-          unsigned char* lp = smem + row * PRS + col * PCB + ((cc ^ swz(col)) << 4);
-          uint4 v = *reinterpret_cast<const uint4*>(lp);
-          if constexpr (!RSC) {
-            const uint4 s = sreg[q - q0];
-            const uint32_t vv[4] = {v.x, v.y, v.z, v.w}, ss[4] = {s.x, s.y, s.z, s.w};
-            uint32_t rr[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-              rr[e] = pack_bf16x2(relu_nan(__builtin_bit_cast(float, vv[e] << 16) + __builtin_bit_cast(float, ss[e] << 16)),
-                                  relu_nan(__builtin_bit_cast(float, vv[e] & 0xffff0000u) + __builtin_bit_cast(float, ss[e] & 0xffff0000u)));
-            v = ok ? make_uint4(rr[0], rr[1], rr[2], rr[3]) : make_uint4(0, 0, 0, 0);
-            *reinterpret_cast<uint4*>(lp) = v;
-          }
-          if (ok && row >= 1 && row <= PTH) *reinterpret_cast<uint4*>(yout + run0 + (long)idx * 16) = v;
-        }
-      };
-      __builtin_amdgcn_sched_barrier(0);
-      fetch(0, NH);
+      stamp(4);
       __syncthreads();   // the image holds bn2 * gate (or, RSC, the finished Y)
-      finish(0, NH);
-      __builtin_amdgcn_sched_barrier(0);
-      fetch(NH, NIT);
-      finish(NH, NIT);
+#pragma unroll
+      for (int q = 0; q < NIT; ++q) {
+        const int idx = tid + q * 256;
+        if (idx >= NCH) break;
+        const int p = idx / CPR, cc = idx % CPR, row = p / PW, col = p % PW, grow = ho0 - 1 + row;
+        const bool ok = grow >= 0 && grow < hb;
+        unsigned char* lp = smem + row * PRS + col * PCB + ((cc ^ swz(col)) << 4);
+        uint4 v = *reinterpret_cast<const uint4*>(lp);
+        if constexpr (!RSC) {
+          const uint4 sv = sreg[q];
+          const uint32_t vv[4] = {v.x, v.y, v.z, v.w}, ss[4] = {sv.x, sv.y, sv.z, sv.w};
+          uint32_t rr[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            rr[e] = pack_bf16x2(relu_nan(__builtin_bit_cast(float, vv[e] << 16) + __builtin_bit_cast(float, ss[e] << 16)),
+                                relu_nan(__builtin_bit_cast(float, vv[e] & 0xffff0000u) + __builtin_bit_cast(float, ss[e] & 0xffff0000u)));
+          v = ok ? make_uint4(rr[0], rr[1], rr[2], rr[3]) : make_uint4(0, 0, 0, 0);
+          *reinterpret_cast<uint4*>(lp) = v;
+        }
+        if (ok && row >= 1 && row <= PTH) *reinterpret_cast<uint4*>(yout + run0 + (long)idx * 16) = v;
+      }
     }
+    stamp(5);
     __syncthreads();   // Y complete in the image
+    stamp(6);
     __builtin_amdgcn_s_setprio(0);
 
     // ================= phase B: conv1 of the next block on the Y image, statistics form (conv3x3.hip B_L1, FORM_STATS) =================
@@ -342,6 +359,7 @@ __global__ __launch_bounds__(256, 2) void conv_pair_l1_kernel(ConvPairArgs a) {
       }
     }
     __builtin_amdgcn_s_setprio(3);
+    stamp(7);
     const int mvalid = (hb - ho0) * PW < PMTB ? (hb - ho0) * PW : PMTB;
     const size_t gpos0 = ((size_t)b * a.H + ho0) * PW;
     __syncthreads();   // every wave is done with the Y image
@@ -383,6 +401,7 @@ __global__ __launch_bounds__(256, 2) void conv_pair_l1_kernel(ConvPairArgs a) {
       }
     }
     __syncthreads();   // output tile complete
+    stamp(8);
     auto lds_elem = [&](int m, int c) { return bf16_to_f32(*reinterpret_cast<const uint16_t*>(smem + m * POPS + c * 2)); };
     if (tid < 2 * PC) {   // edge sums for the zero padding of the conv that follows (conv3x3.hip, statistics form: same chains, same order)
       const int side = tid >= PC ? 1 : 0;
@@ -425,6 +444,7 @@ __global__ __launch_bounds__(256, 2) void conv_pair_l1_kernel(ConvPairArgs a) {
         *reinterpret_cast<uint4*>(oout + run0 + (unsigned)idx * 16u) = *reinterpret_cast<const uint4*>(smem + lane_lds + q * (256 / CPR) * POPS);
       }
     }
+    stamp(9);
     return true;
   };
   __syncthreads();   // conv1's weights are in LDS

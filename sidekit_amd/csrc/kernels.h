@@ -67,7 +67,7 @@ int launch_conv(int shape, int dtype, const ConvArgs& a, hipStream_t st);
 size_t conv_pack_bytes(const ConvGeom& g);
 void conv_pack_weights(const ConvGeom& g, const float* w, int kh_kw, void* dst);
 
-// ---- conv_pair.hip ------------------------------------------------------------------------
+// ---- conv_pair.hip (A/B builds only) ----------------------------------------------------------
 // conv2 of BasicBlock k + conv1 of BasicBlock k + 1 of layer 1 in one kernel (bf16): the block output Y_k passes from conv2's epilogue to conv1's
 // k-loop through LDS and is written to HBM once, never read back (res_net.py:309-320, two consecutive blocks).  Same numbers, bit for bit, as
 // launch_conv(residual form) followed by launch_conv(statistics form).
@@ -89,6 +89,7 @@ struct ConvPairArgs {
   Lens lens;             // rows per utterance (layer 1: the feature frames)
   int B, H;              // utterances, allocated rows
   int persist_cap;
+  unsigned long long* stamps;   // diagnostics only (sk_bench_conv shape 48): 16 s_memtime stamps per workgroup (its last item), or nullptr
 };
 int launch_conv_pair(const ConvPairArgs& a, hipStream_t st);
 

@@ -734,9 +734,11 @@ static int half_from_feats(xt_handle* h, Lane& ln, const float* feats, long sb, 
   { ProfScope ps(h, XT_PROF_STEM, st); SK_TRY(launch_stem(feats, sb, sf, stt, h->stem_w, h->stem_shift, X, dt, m.lens, B, T, st)); }
   SK_TRY(tap(h, "stem", X, act_bytes, st));
   int prev_li = 0;
-  // layer 1, bf16: conv2 of block k and conv1 of block k + 1 run as ONE kernel (conv_pair.hip) -- Y_k reaches conv1 through LDS and HBM sees 13
-  // instead of 15 activation passes for the layer.  Same bits as the two launches (A/B builds: SIDEKIT_AMD_NO_PAIR=1 runs those).
-  const bool use_pair = dt == DT_BF16 && !h->shortcut_tensor && !h->gate_prologue && !SK_AB_GETENV("SIDEKIT_AMD_NO_PAIR");
+  // A/B builds, SIDEKIT_AMD_PAIR=1 (round 6): layer 1, bf16: conv2 of block k and conv1 of block k + 1 as ONE kernel (conv_pair.hip) -- Y_k reaches
+  // conv1 through LDS and HBM sees 13 instead of 15 activation passes for the layer.  Same bits as the two launches, and slower (1.84 vs 1.58 ms per
+  // step for the layer: the fused workgroup's chain of barrier-separated memory phases is twice as long and a CU still holds only two of them,
+  // profiles/r06_conv_pair_L1.txt): not in the product library.
+  const bool use_pair = dt == DT_BF16 && !h->shortcut_tensor && !h->gate_prologue && SK_AB_GETENV("SIDEKIT_AMD_PAIR") != nullptr;
   bool o1_ready = false;   // this block's conv1 has already run (second half of the previous block's pair kernel)
   for (size_t bi = 0; bi < h->blocks.size(); ++bi) {
     Block& b = h->blocks[bi];
@@ -797,6 +799,7 @@ static int half_from_feats(xt_handle* h, Lane& ln, const float* feats, long sb, 
       ProfScope ps(h, XT_PROF_SE_RES, st);
       SK_TRY(launch_se_pre(se, st));
     }
+#ifdef SK_AB
     const bool pair = use_pair && li == 0 && bi + 1 < h->blocks.size() && h->blocks[bi + 1].li == li && (!first || inplace_sc);
     if (pair) {
       const Block& nb = h->blocks[bi + 1];
@@ -809,7 +812,7 @@ static int half_from_feats(xt_handle* h, Lane& ln, const float* feats, long sb, 
       pa.w1pack = nb.c1.wpack; pa.scale1 = nb.c1.scale; pa.shift1 = nb.c1.shift; pa.o_out = SC;
       pa.se_part = (float*)ln.ws_se.p; pa.col_part = (float*)ln.ws_col.p; pa.edge = (float*)ln.ws_edge.p;
       pa.zeros = h->d_zeros; pa.lens = m.lens; pa.B = B; pa.H = Hl[li]; pa.persist_cap = ln.persist_cap;
-      { ProfScope ps(h, XT_PROF_PAIR_L1, st); SK_TRY(launch_conv_pair(pa, st)); }
+      { ProfScope ps(h, b.c2.shape, st); SK_TRY(launch_conv_pair(pa, st)); }
       // Y_k (O2) is the next block's input, O1_{k+1} (SC) its conv1 output; the two buffers just read are free
       void *old_x = X, *old_o1 = O1;
       X = O2; O1 = SC; O2 = old_x; SC = old_o1;
@@ -817,6 +820,8 @@ static int half_from_feats(xt_handle* h, Lane& ln, const float* feats, long sb, 
       prev_li = li;
       continue;
     }
+#endif
+    (void)use_pair;
     o1_ready = false;
     // conv2 + bn2, * gate, + shortcut, relu -> O2 (the block output)
     a.in = O1; a.wpack = b.c2.wpack; a.scale = b.c2.scale; a.shift = b.c2.shift; a.out = O2;
@@ -1407,8 +1412,9 @@ int xt_get_profile(xt_handle* h, double* ms, int64_t* launches, int32_t reset) {
 
 // Kernel-level timing harness for tuning (diagnostic; not used by the product path): runs one trunk
 // convolution shape `iters` times on zero-initialised buffers and returns the mean device time.
-// shape 48: the layer-1 pair kernel (conv_pair.hip) on random operands; variant bit 0: the first block's in-place shortcut form
-static int bench_conv_pair(int32_t B, int32_t T, int32_t iters, int32_t variant, float* ms_out) {
+#ifdef SK_AB
+// shape 48 (A/B builds): the layer-1 pair kernel (conv_pair.hip) on random operands; variant bit 0: the first block's in-place shortcut form
+static int bench_conv_pair(int32_t B, int32_t T, int32_t iters, int32_t variant, float* ms_out, double* phase_cycles) {
   const size_t act = (size_t)B * T * 80 * 32 * 2, wbytes = 32 * 32 * 9 * 2;
   void *bufs[4] = {nullptr, nullptr, nullptr, nullptr}, *w[3] = {nullptr, nullptr, nullptr}, *zeros = nullptr;
   float *cst = nullptr, *gate = nullptr, *se = nullptr, *colp = nullptr, *edge = nullptr;
@@ -1440,6 +1446,9 @@ static int bench_conv_pair(int32_t B, int32_t T, int32_t iters, int32_t variant,
   if (variant & 1) { pa.sc_in = bufs[1]; pa.sc_wpack = w[2]; pa.sc_shift = cst + 128; } else { pa.shortcut = bufs[1]; }
   pa.y_out = bufs[2]; pa.w1pack = w[1]; pa.scale1 = cst + 64; pa.shift1 = cst + 96; pa.o_out = bufs[3];
   pa.se_part = se; pa.col_part = colp; pa.edge = edge; pa.zeros = zeros; pa.lens = Lens{nullptr, T}; pa.B = B; pa.H = T;
+  unsigned long long* stamps = nullptr;
+  const int nblk = 512;   // at most two persistent workgroups per CU
+  if (phase_cycles) { SK_HIP(hipMalloc((void**)&stamps, (size_t)nblk * 128)); SK_HIP(hipMemset(stamps, 0, (size_t)nblk * 128)); pa.stamps = stamps; }
   hipEvent_t e0, e1;
   SK_HIP(hipEventCreate(&e0)); SK_HIP(hipEventCreate(&e1));
   for (int i = 0; i < 3; ++i) SK_TRY(launch_conv_pair(pa, nullptr));
@@ -1449,6 +1458,21 @@ static int bench_conv_pair(int32_t B, int32_t T, int32_t iters, int32_t variant,
   SK_HIP(hipEventSynchronize(e1));
   SK_HIP(hipEventElapsedTime(ms_out, e0, e1));
   *ms_out /= iters;
+  if (phase_cycles) {   // mean cycles between consecutive stamps (nine phases) of each workgroup's last item; [9] = the item, [10] = its 100-MHz ticks
+    std::vector<unsigned long long> hs((size_t)nblk * 16);
+    SK_HIP(hipMemcpy(hs.data(), stamps, hs.size() * 8, hipMemcpyDeviceToHost));
+    for (int k = 0; k < 11; ++k) phase_cycles[k] = 0;
+    int n = 0;
+    for (int i = 0; i < nblk; ++i) {
+      if (!hs[(size_t)i * 16 + 9]) continue;
+      for (int k = 0; k < 9; ++k) phase_cycles[k] += (double)(hs[(size_t)i * 16 + k + 1] - hs[(size_t)i * 16 + k]);
+      phase_cycles[9] += (double)(hs[(size_t)i * 16 + 9] - hs[(size_t)i * 16]);
+      phase_cycles[10] += (double)hs[(size_t)i * 16 + 15];
+      ++n;
+    }
+    for (int k = 0; k < 11; ++k) phase_cycles[k] /= (n ? n : 1);
+    (void)hipFree(stamps);
+  }
   for (auto p : bufs) (void)hipFree(p);
   for (auto p : w) (void)hipFree(p);
   (void)hipFree(zeros); (void)hipFree(cst); (void)hipFree(gate); (void)hipFree(se); (void)hipFree(colp); (void)hipFree(edge);
@@ -1456,12 +1480,16 @@ static int bench_conv_pair(int32_t B, int32_t T, int32_t iters, int32_t variant,
   return SK_OK;
 }
 
+#endif
+
 int sk_bench_conv(int32_t shape, int32_t dtype, int32_t B, int32_t T, int32_t iters, int32_t variant, float* ms_out, double* phase_cycles) {
   SK_CHECK(ms_out && B > 0 && T > 0 && iters > 0, SK_EARG, "sk_bench_conv: bad arguments");
+#ifdef SK_AB
   if (shape == 48) {
-    SK_CHECK(dtype == XT_BF16 && !phase_cycles, SK_EARG, "sk_bench_conv: the pair kernel is bf16 only and carries no phase stamps");
-    return bench_conv_pair(B, T, iters, variant, ms_out);
+    SK_CHECK(dtype == XT_BF16, SK_EARG, "sk_bench_conv: the pair kernel is bf16 only");
+    return bench_conv_pair(B, T, iters, variant, ms_out, phase_cycles);   // phase_cycles: 11 doubles here
   }
+#endif
   ConvGeom g;
   const int dt = dtype == XT_BF16 ? DT_BF16 : DT_F32;
   SK_TRY(conv_geom(shape, dt, &g));

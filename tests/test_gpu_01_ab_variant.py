@@ -34,4 +34,4 @@ def test_ab_partners_agree_with_the_product_paths():
     print(tail)
     assert proc.returncode == 0, f"A/B partner tests failed in the child ({proc.returncode}):\n{tail}\n{proc.stderr[-2000:]}"
     m = re.search(r"(\d+) passed", proc.stdout)
-    assert m and int(m.group(1)) >= 4, f"expected the four ab_variant tests to run:\n{tail}"
+    assert m and int(m.group(1)) >= 5, f"expected the five ab_variant tests to run:\n{tail}"

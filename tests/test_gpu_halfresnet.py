@@ -346,6 +346,64 @@ def test_in_convolution_gate_forms_give_the_bits_of_the_launch(gpu, monkeypatch)
                       [c for c in SMALL_GRID_CASES if c[0] != 13])
 
 
+@pytest.mark.ab_variant
+def test_layer1_pair_kernel_gives_the_bits_of_the_two_launches(gpu, monkeypatch):
+    """A/B build only (round 6; measured SLOWER than the two launches, profiles/r06_conv_pair_L1.txt, so the product does not carry it): conv2 of
+    block k and conv1 of block k + 1 of layer 1 as ONE kernel (csrc/conv_pair.hip: the block output reaches the next conv1 through LDS;
+    sidekit/nnet/res_net.py:309-320, two consecutive blocks; SIDEKIT_AMD_PAIR=1) against the two stand-alone launches: the stage taps after every
+    layer, the x-vectors and the logits are the same BITS -- the pair kernel's tiles, MFMA order, epilogue arithmetic and SE-sum order are the
+    stand-alone kernels'.  Batches of 1 .. 256; uniform, ragged, clips shorter than one 8-row tile and lengths that leave one valid row in the last
+    tile; a 45-s utterance (563 row tiles); pipelined submits."""
+    def make(env):
+        if env:
+            monkeypatch.setenv("SIDEKIT_AMD_PAIR", "1")
+        m = Xtractor(64, model_archi="halfresnet34", loss="aam", seed=43).to(gpu).eval()
+        m.compute_dtype = "bf16"
+        m(torch.zeros(1, 4000, device="cuda") + 0.01, is_eval=True)
+        if env:
+            monkeypatch.delenv("SIDEKIT_AMD_PAIR")
+        return m
+    plain, paired = make(False), make(True)          # the switch is read per forward: set around every call of `paired`
+    g = torch.Generator(device="cuda").manual_seed(19)
+    names = ["stem", "layer1", "layer2", "layer3", "layer4"]
+
+    def run(m, env, wav, lens):
+        if env:
+            monkeypatch.setenv("SIDEKIT_AMD_PAIR", "1")
+        m.set_debug(True)
+        logits, emb = m(wav, is_eval=True, lengths=lens)
+        taps = m.debug_taps(names)
+        m.set_debug(False)
+        if env:
+            monkeypatch.delenv("SIDEKIT_AMD_PAIR")
+        return logits, emb, taps
+
+    cases = [(1, 64000, None), (3, 48000, [48000, 1290, 31999]), (2, 2400, [2400, 1130]),            # 16 / 8 frames: two tiles / exactly one tile
+             (5, 20000, [20000, 1280 + 159, 1280 * 2, 1280 * 2 + 160, 19999]),                      # 9, 17, 18 rows: one / two valid rows in the last tile
+             (1, 45 * 16000, None), (40, 32000, "ragged"), (256, 16000, None), (130, 24000, "ragged")]
+    for B, L, lens in cases:
+        wav = 0.1 * torch.randn(B, L, device="cuda", generator=g)
+        if lens == "ragged":
+            lens = torch.randint(L // 4, L + 1, (B,), generator=torch.Generator().manual_seed(B * 5 + 3)).tolist()
+        (la, ea, ta), (lb, eb, tb) = run(paired, True, wav, lens), run(plain, False, wav, lens)
+        for n in names:
+            assert numpy.array_equal(ta[n], tb[n]), (B, L, n, int((ta[n] != tb[n]).sum()))
+        same = lambda x, y: torch.equal(x, y) or bool(((x == y) | (torch.isnan(x) & torch.isnan(y))).all())      # T' = 1 clips are NaN in both (the reference's unbiased std)
+        assert same(ea, eb) and same(la, lb), (B, L)
+    # two batches in flight (one workgroup per CU for the persistent grids: persist_cap)
+    w = [0.1 * torch.randn(256, 32000, device="cuda", generator=g) for _ in range(3)]
+    want = [plain(x, is_eval=True)[1].clone() for x in w]
+    monkeypatch.setenv("SIDEKIT_AMD_PAIR", "1")
+    t = [paired.submit(w[0]), paired.submit(w[1])]
+    got = [paired.collect(t[0])[1]]
+    t.append(paired.submit(w[2]))
+    got += [paired.collect(t[1])[1], paired.collect(t[2])[1]]
+    torch.cuda.synchronize()
+    monkeypatch.delenv("SIDEKIT_AMD_PAIR")
+    for a, b in zip(got, want):
+        assert torch.equal(a, b)
+
+
 def test_very_short_clips_as_the_first_call(gpu):
     """A batch of 0.05-0.16 s clips (6-16 frames: ONE row tile per layer, T' = 1-2) as a fresh model's first call -- the
     workspace is then sized by that shape alone (the SE-statistics buffers were once under-reserved for it) -- against each clip
