@@ -5,6 +5,9 @@ import torch
 from sidekit_amd import _lib
 if os.environ.get('SK_LIB'):  # A/B against another build of the library
     _lib.LIB_PATH = os.path.abspath(os.environ['SK_LIB'])
+elif len(sys.argv) > 1 and any(int(x) >= 11 and int(x) not in (42, 43) for x in sys.argv[1].split(",")):
+    # the alternative shapes (11-41, 44-47) and the layer-1 pair kernel (48) exist in the A/B build of the library only (csrc/Makefile `make ab`)
+    _lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), "libsidekit_amd_ab.so")
 lib = _lib.lib()
 torch.cuda.init(); torch.zeros(1).cuda()
 names = list(_lib.PROF_NAMES[:11]) + ['X0(L1 3WG)', 'X1(L2 2WG)', 'X2(L3 2WG padded)', 'X3(L4 TH16)', 'X4(L3 r01 linear)', 'X5(L4 r01 linear)', 'X6(L2 r01 linear)', 'X7(L1 r01 linear)', 'X8(L3 GRID 32x32x16)', 'X9(L4 DENSE 32x32x16)', 'X10(L2 GRID 32x32x16)', 'X11(L1 GRID 32x32x16)', 'X12(L1 direct-store epilogue)', 'X13(L4A TH4 3WG)', 'X14(L3A TH2 3WG)', 'X15(L4A TH4 4WG)', 'X16(L3A TH2 4WG)', 'X17(L2A planar 2x8)', 'X18(L3A planar 4x4)', 'X19(L4A planar 8x2)', 'X20(L1 TH4 2 waves)', 'X21(L1 TH4 4 waves)', 'X22(L2 ring 3)', 'X23(L3 ring 3)', 'X24(L4 8 waves)', 'X25(L2A r03 row-major)', 'X26(L3A r03 row-major)', 'X27(L4A r03 row-major)', 'X28(L3A planar M16 occ3)', 'X29(L2A planar M16 occ2)', 'X30(L4A planar M16 occ3)']
