@@ -21,10 +21,11 @@ prints ONE JSON line.  Two extra objects ride on that line:
                on a bounded sample at batch 16 and batch 1 (rank 0, N = 1 only).
 
 The timed region runs the PRODUCT configuration of a corpus run: batches are issued through `Xtractor.submit` / `collect`
-(`xt_forward_begin` / `xt_forward_end`), two WHOLE batches in flight on two streams of the handle, half a step apart -- what
-`sidekit_amd.pipeline.StreamingExtractor` does with the batches of a wav.scp.  A step submits one batch and collects the one submitted a
-step earlier; every batch submitted inside the timed region is collected inside it.  (`--pipeline 1` times one forward at a time: the
-two-lane split of a batch, `xt_set_lanes`.)  Either way kernels of two batches / half batches overlap and one kernel's duration says
+(`xt_forward_begin` / `xt_forward_end`), `Xtractor.pipeline_depth` (2) WHOLE batches in flight, each on a stream of the handle, half a step apart -- what
+`sidekit_amd.pipeline.StreamingExtractor` does with the batches of a wav.scp.  A step submits one batch and collects the one submitted
+depth - 1 steps earlier; every batch submitted inside the timed region is collected inside it.  (`--pipeline 1` times one forward at a time:
+the two-lane split of a batch, `xt_set_lanes`; `--pipeline 3`: three in flight, +0.3-1.1 % here and -13 % for the streaming extractor, profiles/r06_pipeline_depth.txt.)  Either way kernels of
+several batches / half batches overlap and one kernel's duration says
 nothing about that kernel.  The roofline object therefore comes from a second region of the same K steps, one forward at a time on
 one stream (`roofline.measured_in` says so), and `profiles/` holds the rocprofv3 trace of the serial run.  `roofline.traffic` is not
 observed by this run: it is replayed from `profiles/traffic.json` (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command),
@@ -325,8 +326,9 @@ def main():
     ap.add_argument("--arch", default="halfresnet34", choices=["halfresnet34", "xvector"])
     ap.add_argument("--ragged", action="store_true", help="variable-length 2-10 s utterances (BASELINE configs[3] with --arch xvector --dtype fp32 --batch 512)")
     ap.add_argument("--lanes", type=int, default=0, choices=[0, 1, 2], help="0: the library default (two-lane forward), 1: serial, 2: two lanes (only without --pipeline)")
-    ap.add_argument("--pipeline", type=int, default=2, choices=[1, 2], help="2 (default): the steps are issued through Xtractor.submit / collect, two whole batches in flight on two "
-                    "streams of the handle (what the streaming extractor does); 1: one forward at a time (the two-lane split of a batch)")
+    ap.add_argument("--pipeline", type=int, default=0, choices=[0, 1, 2, 3], help="0 (default): the steps are issued through Xtractor.submit / collect with the library's "
+                    "default number of whole batches in flight (Xtractor.pipeline_depth = 2; what the streaming extractor does); 2 / 3: that many; 1: one forward at a time "
+                    "(the two-lane split of a batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--dry-run", action="store_true", help="CPU/gloo stand-in of the loop (plumbing test, not a measurement)")
@@ -377,7 +379,9 @@ def main():
     gathers = [0]
     in_flight = []
     pending = []           # tickets of submitted, not yet collected batches (pipeline 2)
-    pipelined = args.pipeline > 1
+    pipelined = args.pipeline != 1
+    if args.pipeline > 1:
+        model.pipeline_depth = args.pipeline
 
     def gather(emb):
         k = gathers[0]
@@ -527,7 +531,7 @@ def main():
             torch.cuda.synchronize(dev)
             one_at_a_time_ms = (time.perf_counter() - t0) / args.steps * 1e3
         measured_in = (f"a second region of {args.steps} steps, one forward at a time on one stream (xt_set_lanes 1, {serial_ms:.3f} ms per step), run after the "
-                       f"timed region: in the timed region kernels of " + ("two batches in flight" if pipelined else f"the {lanes} parts of a batch") + " overlap")
+                       f"timed region: in the timed region kernels of " + (f"{model.pipeline_depth} batches in flight" if pipelined else f"the {lanes} parts of a batch") + " overlap")
     if rank == 0:
         T = 1 + L // (160 if args.arch == "halfresnet34" else 512)
         issue = (f"Xtractor.submit / collect ({model.pipeline_depth} whole batches in flight; each batch is the forward of Xtractor.forward(is_eval=True))" if pipelined
@@ -579,7 +583,7 @@ def main():
                     r["serial_ms_per_step"] = serial_ms
                 # which schedule `frac` belongs to, at a glance: kernel durations mean something only when one kernel runs at a time
                 r["schedule"] = {"of_frac": "serial: one forward at a time on ONE stream (xt_set_lanes 1)" if serial_ms is not None else "the timed region itself (serial lanes)",
-                                 "serial_ms_per_step": serial_ms, "of_value": ("pipelined: two whole batches in flight on two streams" if pipelined else f"one forward at a time, {lanes} lane(s)"),
+                                 "serial_ms_per_step": serial_ms, "of_value": (f"pipelined: {model.pipeline_depth} whole batches in flight, each on a stream of the handle" if pipelined else f"one forward at a time, {lanes} lane(s)"),
                                  "value_ms_per_step": dt / args.steps * 1e3, "one_forward_at_a_time_ms_per_step": one_at_a_time_ms}
             out["roofline"] = r
         if world == 1 and not args.no_cpu_baseline:

@@ -143,7 +143,7 @@ def main(argv=None, model=None, scoring=None, keep=None):
     sync()
     t0 = time.perf_counter()
     blocks, tickets = [], []
-    pipelined = dev.type == "cuda" and hasattr(model, "submit")     # two whole batches in flight (Xtractor.submit / collect)
+    pipelined = dev.type == "cuda" and hasattr(model, "submit")     # whole batches in flight (Xtractor.submit / collect; model.pipeline_depth)
     for k in range(n_batches):
         lo = start + k * args.batch
         hi = min(lo + args.batch, stop)

@@ -229,9 +229,11 @@ class StreamingExtractor:
         self.norm_embedding = norm_embedding
         self.device = torch.device(model.device)
         self.cuda = self.device.type == "cuda"
-        self.ring = [_Staging(self.device) for _ in range(self.pending + self.stage_ahead + 1)]
         self.copy_stream = torch.cuda.Stream(self.device) if self.cuda else None
-        self.pipelined = self.cuda and hasattr(model, "submit")   # two whole batches in flight (Xtractor.submit / collect)
+        self.pipelined = self.cuda and hasattr(model, "submit")   # whole batches in flight (Xtractor.submit / collect)
+        # staging slots: the batches whose forwards are in flight beyond the newest one, those waiting for their read-back, those staged ahead, + 1
+        in_flight = max(1, getattr(model, "pipeline_depth", 2) - 1) if self.pipelined else 1
+        self.ring = [_Staging(self.device) for _ in range(self.pending + self.stage_ahead + in_flight)]
         self.stats = {"utterances": 0, "batches": 0, "samples": 0, "padded_samples": 0, "native_reads": 0}
 
     def _resample(self, sample, rate):
