@@ -24,7 +24,7 @@ The timed region runs the PRODUCT configuration of a corpus run: batches are iss
 (`xt_forward_begin` / `xt_forward_end`), `Xtractor.pipeline_depth` (2) WHOLE batches in flight, each on a stream of the handle, half a step apart -- what
 `sidekit_amd.pipeline.StreamingExtractor` does with the batches of a wav.scp.  A step submits one batch and collects the one submitted
 depth - 1 steps earlier; every batch submitted inside the timed region is collected inside it.  (`--pipeline 1` times one forward at a time:
-the two-lane split of a batch, `xt_set_lanes`; `--pipeline 3`: three in flight, +0.3-1.1 % here and -13 % for the streaming extractor, profiles/r06_pipeline_depth.txt.)  Either way kernels of
+the two-lane split of a batch, `xt_set_lanes`; `--pipeline 3`: three in flight, +0.3-1.1 % here and -10-13 % for the streaming extractor, profiles/r06_pipeline_depth.txt.)  Either way kernels of
 several batches / half batches overlap and one kernel's duration says
 nothing about that kernel.  The roofline object therefore comes from a second region of the same K steps, one forward at a time on
 one stream (`roofline.measured_in` says so), and `profiles/` holds the rocprofv3 trace of the serial run.  `roofline.traffic` is not

@@ -165,8 +165,8 @@ class Xtractor:
 
     # batches in flight.  Two is where the gain is (5.80 -> 5.56 ms per batch of 256, round 4).  A third adds 0.3-1.1 % on resident inputs (round 6, alternating
     # runs on two boxes: 46.12 / 46.14 -> 46.49 / 46.63 k and 45.24 / 45.39 -> 45.74 / 45.52 k x-vectors/s) and COSTS the streaming extractor 13 % (38.5 / 39.6 ->
-    # 34.4 / 33.6 k files/s): with the caller's stream and the extractor's copy stream, three slot streams are five streams of the process on four hardware
-    # queues -- the same cliff four batches in flight hit in bench.py (42.4-42.5 k).  profiles/r06_pipeline_depth.txt
+    # 34.4 / 33.6 k files/s: its copy stream and read-backs then share the device with three forwards); four in flight lose 8 % in bench.py itself (42.4-42.5 k);
+    # GPU_MAX_HW_QUEUES=8 changes none of it.  profiles/r06_pipeline_depth.txt
     pipeline_depth = _depth_from_env.__func__()
 
     def submit(self, x, lengths=None, norm_embedding=True):
