@@ -280,14 +280,16 @@ def test_cosine_histograms_match_the_score_matrix(gpu):
     assert 0.01 < eer_x < 0.4 and abs(eer_h - eer_x) < 5e-4, (eer_h, eer_x)
     # finer bins (round 6, tests/test_gpu_eer_dtype.py): `bins` a multiple of HIST_BINS - 2 = that many passes of the kernel over slices of [lo, hi)
     # with one guard bin either side; scores outside the range land in the end bins.  Against numpy on the score matrix with the same edges: a
-    # score within float32 rounding of an edge may sit in the neighbouring bin (the kernel bins (s - lo_pass) * scale in float32)
+    # score within float32 rounding of an edge may sit in the neighbouring bin (the kernel bins (s - lo_pass) * scale in float32; a bin is 4e-5 wide,
+    # so about one score in 400 is that close to an edge) -- each such score moves ONE value of the cumulative counts by one, hence the bound on the
+    # cumulative difference (observed: 4 of 10^6 pairs), not on the bins
     lo, hi, nf = float(S[off].min()) + 0.05, float(S[off].max()) - 0.02, 3 * (nb - 2)      # some scores below lo and above hi
     hft, hfn = iv_scoring.cosine_histograms(X, X, lab, lab, self_offset=0, lo=lo, hi=hi, bins=nf)
     assert hft.shape == hfn.shape == (nf,) and int(hft.sum() + hfn.sum()) == N * N - N
     want = numpy.clip(numpy.floor((S.astype(numpy.float64) - lo) * (nf / (hi - lo))).astype(numpy.int64), 0, nf - 1)
     for got, sel in ((hft, tar & off), (hfn, ~tar)):
         ref = numpy.bincount(want[sel], minlength=nf)
-        assert int(numpy.abs(numpy.cumsum(got.astype(numpy.int64)) - numpy.cumsum(ref)).max()) <= 3 and int(got[0]) >= int((S[sel] < lo).sum()) - 3
+        assert int(numpy.abs(numpy.cumsum(got.astype(numpy.int64)) - numpy.cumsum(ref)).max()) <= 16 and int(got[0]) >= int((S[sel] < lo).sum()) - 16
     assert abs(eer_from_histograms(hft, hfn) - eer_x) < 5e-4
     with pytest.raises(AssertionError):
         iv_scoring.cosine_histograms(X, X, lab, lab, bins=10000)
