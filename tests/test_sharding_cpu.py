@@ -208,6 +208,15 @@ def test_shard_extract_score_driver_on_two_ranks(tmp_path, monkeypatch):
     assert two["all_pairs"] == one["all_pairs"]
     for k in ("cosine_eer", "plda_eer", "all_pairs_eer"):
         assert two[k] == one[k], (k, one[k], two[k])
+    # round 6: two runs that are to be compared share their histogram edges (--hist-range), and --seed draws another corpus
+    assert two["all_pairs_hist_range"] == one["all_pairs_hist_range"] and one["all_pairs_hist_bins"] == 8192
+    lo, hi = one["all_pairs_hist_range"]
+    same = shard_extract_score.main(_DRIVER_ARGS + ["--hist-range", repr(lo), repr(hi)], model=_BandEnergyXtractor(), scoring=_CpuScoring)
+    assert same["all_pairs_hist_range"] == [lo, hi] and same["all_pairs_eer"] == one["all_pairs_eer"]
+    wide = shard_extract_score.main(_DRIVER_ARGS + ["--hist-range", "-1.0", "1.0"], model=_BandEnergyXtractor(), scoring=_CpuScoring)
+    assert wide["all_pairs_hist_range"] == [-1.0, 1.0] and wide["all_pairs"] == one["all_pairs"] and abs(wide["all_pairs_eer"] - one["all_pairs_eer"]) < 0.02
+    other = shard_extract_score.main(_DRIVER_ARGS + ["--seed", "3"], model=_BandEnergyXtractor(), scoring=_CpuScoring)
+    assert other["all_pairs"] == one["all_pairs"] and other["cosine_eer"] != one["cosine_eer"]
     # the injected-module switch is not a fallback: the product entry point refuses a CPU device
     import pytest
     with pytest.raises(RuntimeError, match="no CPU fallback"):
