@@ -12,7 +12,7 @@ lib = _lib.lib()
 torch.cuda.init(); torch.zeros(1).cuda()
 names = list(_lib.PROF_NAMES[:11]) + ['X0(L1 3WG)', 'X1(L2 2WG)', 'X2(L3 2WG padded)', 'X3(L4 TH16)', 'X4(L3 r01 linear)', 'X5(L4 r01 linear)', 'X6(L2 r01 linear)', 'X7(L1 r01 linear)', 'X8(L3 GRID 32x32x16)', 'X9(L4 DENSE 32x32x16)', 'X10(L2 GRID 32x32x16)', 'X11(L1 GRID 32x32x16)', 'X12(L1 direct-store epilogue)', 'X13(L4A TH4 3WG)', 'X14(L3A TH2 3WG)', 'X15(L4A TH4 4WG)', 'X16(L3A TH2 4WG)', 'X17(L2A planar 2x8)', 'X18(L3A planar 4x4)', 'X19(L4A planar 8x2)', 'X20(L1 TH4 2 waves)', 'X21(L1 TH4 4 waves)', 'X22(L2 ring 3)', 'X23(L3 ring 3)', 'X24(L4 8 waves)', 'X25(L2A r03 row-major)', 'X26(L3A r03 row-major)', 'X27(L4A r03 row-major)', 'X28(L3A planar M16 occ3)', 'X29(L2A planar M16 occ2)', 'X30(L4A planar M16 occ3)']
 Ts = {0: 401, 1: 401, 2: 401, 3: 401, 4: 201, 5: 201, 6: 201, 7: 101, 8: 101, 9: 101, 10: 51, 11: 401, 12: 201, 13: 101, 14: 51, 15: 101, 16: 51, 17: 201, 18: 401, 19: 101, 20: 51, 21: 201, 22: 401, 23: 401, 24: 101, 25: 201, 26: 101, 27: 201, 28: 401, 29: 201, 30: 101, 31: 401, 32: 401, 33: 201, 34: 101, 35: 51, 36: 401, 37: 201, 38: 101, 39: 201, 40: 401, 41: 101}
-names += [f'shape{i}' for i in range(len(names), 49)]; names[48] = 'PAIR_L1 (conv2 + next conv1)'; Ts[48] = 401
+names += [f'shape{i}' for i in range(len(names), 49)]; names[48] = 'PAIR_L1 (conv2 + next conv1)'; Ts[48] = 401; names += ['X34(L3A TH8 1WG)']; Ts[49] = 201
 shapes = [int(x) for x in sys.argv[1].split(",")] if len(sys.argv) > 1 else [0, 4, 7, 10]
 STAMPS = os.environ.get("STAMPS", "0") == "1"
 variants = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0, 1, 2, 3, 4, 6]
