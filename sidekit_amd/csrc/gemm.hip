@@ -323,10 +323,17 @@ __global__ __launch_bounds__(128) void gemm_bf16_kernel(GemmArgs g) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) R.w[q] = *reinterpret_cast<const uint4*>(wp[q] + k0);
   };
-  f32x16 acc;
+  f32x16 acc, tot;
 #pragma unroll
-  for (int q = 0; q < 16; ++q) acc[q] = 0.f;
-  const int nk = g.K / BKH;
+  for (int q = 0; q < 16; ++q) { acc[q] = 0.f; tot[q] = 0.f; }
+  // K is summed in g.kslices slices of `per` k-tiles (a function of K alone, launch_gemm): slice sums are added in slice order, ((0 + s0) + s1) + ...
+  // Below 512 rows the slices run as blockIdx.y (round 6: attention.0 of ONE utterance was four workgroups walking forty k-tiles each, 21.7 us of a
+  // 0.62-ms forward) and gemm_splitk_epilogue_kernel adds them in that order; above, this workgroup walks all of them and adds them itself --
+  // the same additions, so a row's result does not depend on how many rows share its launch.
+  const int per = (g.K / BKH) / g.kslices;
+  const int kt0 = g.ksplit > 1 ? (int)blockIdx.y * per : 0;      // first k-tile of this workgroup
+  const int nk = g.ksplit > 1 ? per : g.K / BKH;
+  int in_slice = 0;
   // one k-tile from its registers through LDS to the matrix cores; the registers are refilled with k-tile `next` (always: a loop whose
   // loads sit behind a condition gets vmcnt(0) waits, and the tile fetched two steps ahead would be waited for at once)
   auto step = [&](Regs& R, int next) {
@@ -343,26 +350,31 @@ __global__ __launch_bounds__(128) void gemm_bf16_kernel(GemmArgs g) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) *reinterpret_cast<uint4*>(Ws + (srow + q * 16) * LDH + sk8 * 2) = R.w[q];
     __syncthreads();
-    fetch(next * BKH, R);
+    fetch((kt0 + next) * BKH, R);
 #pragma unroll
     for (int kk = 0; kk < BKH; kk += 16) {
       const uint4 a = *reinterpret_cast<const uint4*>(As + r * LDH + (kk + 8 * h) * 2);
       const uint4 b = *reinterpret_cast<const uint4*>(Ws + (wn * 32 + r) * LDH + (kk + 8 * h) * 2);
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
     }
+    if (g.kslices > 1 && ++in_slice == per) {   // a slice is complete (wave-uniform): add it to the running total and start the next one from zero
+#pragma unroll
+      for (int q = 0; q < 16; ++q) { tot[q] += acc[q]; acc[q] = 0.f; }
+      in_slice = 0;
+    }
     __syncthreads();
   };
   Regs R0, R1;
   int kt = 0;
   if (nk & 1) {            // an odd tile count: the first tile on its own, pairs after it
-    fetch(0, R0);
+    fetch(kt0 * BKH, R0);
     step(R0, 0);
     kt = 1;
   }
   const int last = nk - 1;
   if (kt < nk) {
-    fetch(kt * BKH, R0);
-    fetch((kt + 1) * BKH, R1);
+    fetch((kt0 + kt) * BKH, R0);
+    fetch((kt0 + kt + 1) * BKH, R1);
     for (; kt < nk; kt += 2) {   // tiles past the end are clamped to the last one: fetched again, never used
       step(R0, kt + 2 < last ? kt + 2 : last);
       step(R1, kt + 3 < last ? kt + 3 : last);
@@ -373,7 +385,9 @@ __global__ __launch_bounds__(128) void gemm_bf16_kernel(GemmArgs g) {
 #pragma unroll
   for (int q = 0; q < 16; ++q) {
     const int m = m0 + (q & 3) + 8 * (q >> 2) + 4 * h;
-    if (m < g.M) g.C[(long)m * g.ldc + n] = gemm_epilogue(g, acc[q], m, n);
+    if (m >= g.M) continue;
+    if (g.ksplit > 1) g.splitk_ws[((long)blockIdx.y * g.M + m) * g.N + n] = tot[q];      // this slice's sum (0 + s_z); the epilogue kernel adds the slices in order
+    else g.C[(long)m * g.ldc + n] = gemm_epilogue(g, g.kslices > 1 ? tot[q] : acc[q], m, n);
   }
 }
 
@@ -429,21 +443,29 @@ int launch_gemm(const GemmArgs& g_in, hipStream_t s) {
   if (g.l2_done) *g.l2_done = 0;
   g.ksplit = 1; g.kslices = 1;
   g.dbg = SK_AB_ENV_INT("SIDEKIT_AMD_GEMM_DBG", 0);
+  SK_CHECK(g.M > 0 && g.N > 0 && g.K > 0, SK_EARG, "gemm: empty problem %dx%dx%d", g.M, g.N, g.K);
+  if (g.W_bf16 && g.a_mode == A_PLAIN && g.kc == 0 && g.K % BKH == 0 && g.lda % 8 == 0 && g.ldw % 8 == 0) {   // whole k-tiles on the bf16 matrix cores (the model's two: K = 2560, 128)
+    const int nkh = g.K / BKH;
+    g.kslices = (nkh >= 16 && nkh % 8 == 0) ? 8 : 1;                               // K alone decides how the sum is grouped ...
+    g.ksplit = (g.kslices > 1 && g.M <= 512 && g.splitk_ws) ? g.kslices : 1;      // ... M only where the slices run
+    SK_CHECK(g.lda % 4 == 0, SK_EARG, "gemm: lda alignment");
+    const dim3 gridh((unsigned)(cdiv(cdiv(g.M, BMH), 8) * 8 * cdiv(g.N, BN)), (unsigned)g.ksplit);
+    if (g.a_bf16) hipLaunchKernelGGL(gemm_bf16_kernel<true>, gridh, dim3(128), 0, s, g);
+    else hipLaunchKernelGGL(gemm_bf16_kernel<false>, gridh, dim3(128), 0, s, g);
+    SK_HIP(hipGetLastError());
+    if (g.ksplit > 1) {
+      hipLaunchKernelGGL(gemm_splitk_epilogue_kernel, dim3((unsigned)(((long)g.M * g.N + 255) / 256)), dim3(256), 0, s, g);
+      SK_HIP(hipGetLastError());
+    }
+    return SK_OK;
+  }
   if (g.splitk_ws && g.K >= 1024) {   // the summation order depends on K alone; M only decides where the slices run
     const int nk = (g.K + BK - 1) / BK;
     g.kslices = nk / 8 < 32 ? (nk / 8 > 1 ? nk / 8 : 1) : 32;   // >= 8 k-tiles per slice, at most 32 slices
     if (g.M <= 512) g.ksplit = g.kslices;
   }
-  SK_CHECK(g.M > 0 && g.N > 0 && g.K > 0, SK_EARG, "gemm: empty problem %dx%dx%d", g.M, g.N, g.K);
   SK_CHECK(g.K % 4 == 0 && g.ldw % 4 == 0, SK_EARG, "gemm: K=%d / ldw=%ld must be multiples of 4", g.K, g.ldw);
   SK_CHECK(g.a_mode != A_PLAIN || (g.lda % 4 == 0 && g.kc % 4 == 0), SK_EARG, "gemm: lda/kc alignment");
-  if (g.W_bf16 && g.a_mode == A_PLAIN && g.kc == 0 && g.K % BKH == 0 && g.lda % 8 == 0 && g.ldw % 8 == 0 && g.ksplit == 1) {   // whole k-tiles (the model's two: K = 2560, 128)
-    const dim3 gridh((unsigned)(cdiv(cdiv(g.M, BMH), 8) * 8 * cdiv(g.N, BN)));
-    if (g.a_bf16) hipLaunchKernelGGL(gemm_bf16_kernel<true>, gridh, dim3(128), 0, s, g);
-    else hipLaunchKernelGGL(gemm_bf16_kernel<false>, gridh, dim3(128), 0, s, g);
-    SK_HIP(hipGetLastError());
-    return SK_OK;
-  }
   if (g.ksplit == 1 && g.M >= 2048 && g.N >= 128 && g.a_mode == A_PLAIN && !g.a_bf16 && !SK_AB_GETENV("SIDEKIT_AMD_GEMM64")) {   // large problem: 128 x 128 tiles (same numbers)
     dim3 grid2(cdiv(g.M, BM2), cdiv(g.N, BN2));
     if (g.kslices > 1) hipLaunchKernelGGL(gemm128_kernel<true>, grid2, dim3(256), 0, s, g);

@@ -856,6 +856,7 @@ static int half_from_feats(xt_handle* h, Lane& ln, const float* feats, long sb, 
   g1.A = X; g1.a_bf16 = xbf; g1.lda = D; g1.a_rows = R; g1.W = h->att_w1x; g1.ldw = D; g1.C = (float*)ln.ws_h.p; g1.ldc = 128;
   g1.M = R; g1.N = 128; g1.K = D; g1.rowbias = (const float*)ln.ws_rb.p; g1.rows_per_group = H4;
   g1.act = ACT_RELU_BN_TANH; g1.scale = h->att_bn_scale; g1.shift = h->att_bn_shift; g1.W_bf16 = h->att_w1x_bf16;
+  if (xbf && (size_t)8 * 512 * 128 * 4 <= ln.ws_splitk.bytes) g1.splitk_ws = (float*)ln.ws_splitk.p;   // bf16 path, at most 512 rows (a few utterances): K in eight slices side by side (gemm.hip)
   SK_TRY(launch_gemm(g1, st));
   if (xbf && !SK_AB_GETENV("SIDEKIT_AMD_ATT_SEPARATE")) {   // bf16 path: attention.4 + softmax + statistics fused, e never leaves the accumulators
     SK_TRY(launch_att_fused(X, (const float*)ln.ws_h.p, h->att_w2_bf16, h->att_b2, D, D, rs, (float*)ln.ws_pooled.p, B, st));
@@ -1071,7 +1072,10 @@ static int reserve_lane(xt_handle* h, Lane& ln, int32_t max_batch, int64_t max_s
   }
   const size_t E = (size_t)h->cfg.emb_dim;
   SK_TRY(ln.ws_pre.ensure(B * E * 4));
-  SK_TRY(ln.ws_splitk.ensure((size_t)32 * (B < 512 ? B : 512) * 256 * 4));  // split-K partials of the skinny GEMMs (N <= 256)
+  {
+    const size_t skinny = (size_t)32 * (B < 512 ? B : 512) * 256 * 4, att0 = (size_t)8 * 512 * 128 * 4;   // [slices][rows <= 512][N]: the embedding / context GEMMs; attention.0 below 512 rows
+    SK_TRY(ln.ws_splitk.ensure(skinny > att0 ? skinny : att0));
+  }  // split-K partials of the skinny GEMMs (N <= 256)
   if (h->cfg.arch == XT_ARCH_HALFRESNET34) {
     const size_t EB = h->cfg.dtype == XT_BF16 ? 2 : 4;
     for (int i = 0; i < 4; ++i) SK_TRY(ln.ws_act[i].ensure(R * 80 * 32 * EB));
