@@ -10,6 +10,8 @@ from sidekit_amd.pipeline import StreamingExtractor, load_entry
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
 workers = int(sys.argv[2]) if len(sys.argv) > 2 else 12
+if len(sys.argv) > 3:      # A/B: granularity (samples) the workspace reservation rounds a batch's longest utterance up to (1 = exact, the behaviour up to round 5)
+    Xtractor.reserve_round = int(sys.argv[3])
 d = tempfile.mkdtemp(prefix="skwav_", dir="/tmp")
 rs = numpy.random.RandomState(0)
 t0 = time.perf_counter()
@@ -24,7 +26,7 @@ t_write = time.perf_counter() - t0
 dev = torch.device("cuda", 0)
 m = Xtractor(7205, model_archi="halfresnet34", loss="aam", seed=1234).to(dev).eval()
 m.compute_dtype = "bf16"
-out = {"files": N, "seconds_of_audio": None, "write_s": t_write, "decode_workers": workers}
+out = {"files": N, "seconds_of_audio": None, "write_s": t_write, "decode_workers": workers, "reserve_round": Xtractor.reserve_round}
 # (a) one file at a time
 n_a = min(N, 512)
 m(torch.zeros(1, 64000, device=dev), is_eval=True)
@@ -37,9 +39,9 @@ for k, p in entries[:n_a]:
 out["per_file_loop_files_per_s"] = n_a / (time.perf_counter() - t0)
 # (b) streaming
 for bs in (256,):
-    ex = StreamingExtractor(m, batch_size=bs, window=8, workers=workers, pending=2)
+    ex = StreamingExtractor(m, batch_size=bs, window=8, workers=workers)
     dict(ex.run(iter(entries[:1024])))                      # warm-up: workspace, pinned buffers, page cache
-    ex = StreamingExtractor(m, batch_size=bs, window=8, workers=workers, pending=2)
+    ex = StreamingExtractor(m, batch_size=bs, window=8, workers=workers)
     acc = {}
     def timed(name):                                     # where the host time goes (wall time inside each stage, threads overlap)
         fn = getattr(ex, name)

@@ -168,6 +168,14 @@ class Xtractor:
     # 34.4 / 33.6 k files/s: its copy stream and read-backs then share the device with three forwards); four in flight lose 8 % in bench.py itself (42.4-42.5 k);
     # GPU_MAX_HW_QUEUES=8 changes none of it.  profiles/r06_pipeline_depth.txt
     pipeline_depth = _depth_from_env.__func__()
+    # Workspaces are sized for a batch's longest utterance rounded UP to a whole second of samples: a corpus streams batches whose maxima creep up by a few
+    # samples at a time, and every new record otherwise costs a device synchronisation + the reallocation of every buffer of every slot in the middle of the
+    # run (round 6: 16 384 files of 3-5 s: 37-39 k -> see profiles/r06_pipeline_bench.json).  At most one second of activations per utterance more memory.
+    reserve_round = 16000
+
+    def _round_up(self, L):
+        r = max(1, int(self.reserve_round))
+        return -(-int(L) // r) * r
 
     def submit(self, x, lengths=None, norm_embedding=True):
         """Queue ``forward(x, is_eval=True)`` WITHOUT waiting for it on the caller's stream and return a ticket for :meth:`collect`.
@@ -183,11 +191,12 @@ class Xtractor:
         lib = _lib.lib()
         shapes = self._slot_shapes.setdefault(key, [])
         if not any(b >= B and l >= L for b, l in shapes):
+            Lr = self._round_up(L)
             with torch.cuda.device(self.device):
                 torch.cuda.synchronize(self.device)
-                _lib.check(lib.xt_reserve_slots(h, self.pipeline_depth, B, L))
-            shapes[:] = [(b, l) for b, l in shapes if not (b <= B and l <= L)] + [(B, L)]
-            self._reserved[key] = [(b, l) for b, l in self._reserved[key] if not (b <= B and l <= L)] + [(B, L)]
+                _lib.check(lib.xt_reserve_slots(h, self.pipeline_depth, B, Lr))
+            shapes[:] = [(b, l) for b, l in shapes if not (b <= B and l <= Lr)] + [(B, Lr)]
+            self._reserved[key] = [(b, l) for b, l in self._reserved[key] if not (b <= B and l <= Lr)] + [(B, Lr)]
         if len(self._tickets) >= self.pipeline_depth:
             raise RuntimeError(f"submit: {self.pipeline_depth} batches are already in flight -- collect() the oldest first")
         _lib.check(lib.xt_set_norm_embedding(h, 1 if norm_embedding else 0))
@@ -389,6 +398,7 @@ class Xtractor:
         shapes = self._reserved[key]
         if any(b >= B and l >= L for b, l in shapes):
             return
+        L = self._round_up(L)
         with torch.cuda.device(self.device):
             torch.cuda.synchronize(self.device)
             _lib.check(_lib.lib().xt_reserve(h, B, L))

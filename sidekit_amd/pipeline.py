@@ -216,8 +216,11 @@ class StreamingExtractor:
     ``cmd |`` string, an already decoded 1-D array or a callable returning one; ``vec`` is the ``(1, E)`` float32 embedding.  Results arrive batch by
     batch (length-sorted inside a window of ``window * batch_size`` utterances), not in input order."""
 
-    def __init__(self, model, batch_size=256, window=8, workers=None, pending=2, sample_rate=16000, norm_embedding=True, stage_ahead=2,
+    def __init__(self, model, batch_size=256, window=8, workers=None, pending=3, sample_rate=16000, norm_embedding=True, stage_ahead=6,
                  max_samples_per_batch=1 << 26):
+        # pending / stage_ahead: batches waiting for their read-back / staged ahead of the launches.  Round 6 (scripts/pipeline_bench.py, 32 768 files, 8 decode
+        # workers, three alternating runs each, k files/s): 2 / 2 (the default up to round 5) 40.3 / 38.8 / 40.8; 2 / 3 41.3 / 41.3 / 41.0; 3 / 6 41.6 / 41.7 / 41.3;
+        # 4 / 8 41.1 / 40.9 / 40.9 -- a deeper queue rides out the host's jitter (a staging slot is one pinned + one device buffer of a batch of int16 samples)
         self.model = model
         self.batch_size = max(1, int(batch_size))
         self.window = max(1, int(window))
